@@ -1,0 +1,406 @@
+"""ctypes binding of ``libexabm4d.so`` (the C-ABI declared in ``include/exabm4d.h``).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible when a
+compute entry point is called, this module raises.  Contexts are per (process id, device) and are
+created lazily, *after* any ``fork()`` -- the reference calls ``bm4d`` from forked
+``ProcessPoolExecutor`` workers (reference ``scripts/precompute.py:215``).
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_CANDIDATES = [
+    os.environ.get("EXABM4D_LIB", ""),
+    os.path.join(os.path.dirname(_HERE), "csrc", "libexabm4d.so"),
+]
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_u16p = ctypes.POINTER(ctypes.c_uint16)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_vp = ctypes.c_void_p
+
+KEY_EMPTY = 0xFFFFFFFF
+
+
+class Params(ctypes.Structure):
+    """``exabm4d_params`` (include/exabm4d.h)."""
+
+    _fields_ = [
+        ("size", ctypes.c_uint32),
+        ("block", ctypes.c_int32),
+        ("step", ctypes.c_int32),
+        ("search", ctypes.c_int32),
+        ("max_group", ctypes.c_int32),
+        ("lambda_ht", ctypes.c_float),
+        ("c_match_ht", ctypes.c_float),
+        ("c_match_wie", ctypes.c_float),
+        ("kaiser_beta", ctypes.c_float),
+    ]
+
+
+class Transform(ctypes.Structure):
+    """``exabm4d_transform`` (include/exabm4d.h)."""
+
+    _fields_ = [
+        ("size", ctypes.c_uint32),
+        ("kind", ctypes.c_int32),
+        ("wrapped", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("wrap_offset", ctypes.c_double),
+        ("max_count", ctypes.c_double),
+        ("offset", ctypes.c_double),
+        ("scale", ctypes.c_double),
+        ("norm", ctypes.c_double),
+        ("gain", ctypes.c_double),
+        ("read_noise", ctypes.c_double),
+        ("c_inv", ctypes.c_double),
+        ("mn", ctypes.c_double),
+        ("mx", ctypes.c_double),
+        ("clip", ctypes.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/exabm4d.h declares
+_CTX = c_vp
+_PP = ctypes.POINTER(Params)
+_TP = ctypes.POINTER(Transform)
+_I, _F, _SZ = ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+SIGNATURES = {
+    "exabm4d_version": (_I, []),
+    "exabm4d_last_error": (ctypes.c_char_p, [_CTX]),
+    "exabm4d_device_count": (_I, []),
+    "exabm4d_create": (_I, [_I, ctypes.POINTER(_CTX)]),
+    "exabm4d_destroy": (_I, [_CTX]),
+    "exabm4d_set_stream": (_I, [_CTX, c_vp]),
+    "exabm4d_sync": (_I, [_CTX]),
+    "exabm4d_default_params": (_I, [_PP]),
+    "exabm4d_set_option": (_I, [_CTX, ctypes.c_char_p, _I]),
+    "exabm4d_malloc": (_I, [_CTX, _SZ, ctypes.POINTER(c_vp)]),
+    "exabm4d_free": (_I, [_CTX, c_vp]),
+    "exabm4d_memcpy_h2d": (_I, [_CTX, c_vp, c_vp, _SZ]),
+    "exabm4d_memcpy_d2h": (_I, [_CTX, c_vp, c_vp, _SZ]),
+    "exabm4d_memset": (_I, [_CTX, c_vp, _I, _SZ]),
+    "exabm4d_event_create": (_I, [_CTX, ctypes.POINTER(c_vp)]),
+    "exabm4d_event_destroy": (_I, [_CTX, c_vp]),
+    "exabm4d_event_record": (_I, [_CTX, c_vp]),
+    "exabm4d_event_elapsed_ms": (_I, [_CTX, c_vp, c_vp, c_f32p]),
+    "exabm4d_grid_count": (_I, [_I]),
+    "exabm4d_grid_positions": (_I, [_I, c_i32p]),
+    "exabm4d_tables": (_I, [_PP, c_f32p, c_f32p]),
+    "exabm4d_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "exabm4d_blockmatch_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _F, _F, _PP, c_vp]),
+    "exabm4d_match_decode": (_I, [c_u32p, _I, _I, _I, _I, _I, c_i64p, c_f32p,
+                                  ctypes.POINTER(_I)]),
+    "exabm4d_stage_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, c_vp, c_vp]),
+    "exabm4d_normalize_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F, _F]),
+    "exabm4d_denoise_f32_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
+    "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
+    "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
+    "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
+    "exabm4d_transform_forward_f32_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
+    "exabm4d_transform_inverse_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
+    "exabm4d_transform_inverse_f32_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
+    "exabm4d_tile_gather_dev": (_I, [_CTX, c_vp, _I, _I, _I, c_i32p, _I, _I, c_vp]),
+    "exabm4d_tile_accumulate_dev": (_I, [_CTX, c_vp, c_i32p, _I, _I, _I, c_vp, c_vp, _I, _I, _I]),
+    "exabm4d_tile_finalize_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, c_vp, _SZ]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class NativeError(RuntimeError):
+    """libexabm4d.so is missing, or a call into it failed."""
+
+
+def library_path():
+    for p in _LIB_CANDIDATES:
+        if p and os.path.exists(p):
+            return p
+    raise NativeError(
+        "libexabm4d.so not found (looked in %s). Build it with `make -C "
+        "aind-exaspim-image-compression_amd/csrc` or __graft_entry__.build(); there is no "
+        "CPU fallback for the HIP hot path." % [p for p in _LIB_CANDIDATES if p])
+
+
+def lib():
+    """Load the shared library (no GPU needed for this) and bind every symbol."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            L = ctypes.CDLL(library_path())
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+def default_params(**overrides):
+    p = Params()
+    rc = lib().exabm4d_default_params(ctypes.byref(p))
+    if rc:
+        raise NativeError("exabm4d_default_params failed")
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise ValueError(f"unknown BM4D parameter: {k}")
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(obj):
+    """Device pointer of a DeviceBuffer, a torch tensor, an int, or None."""
+    if obj is None:
+        return None
+    if isinstance(obj, DeviceBuffer):
+        return obj.ptr
+    if isinstance(obj, int):
+        return obj
+    if hasattr(obj, "data_ptr"):
+        return int(obj.data_ptr())
+    raise TypeError(f"cannot take a device pointer from {type(obj)!r}")
+
+
+class DeviceBuffer:
+    """A hipMalloc'd region owned through ``exabm4d_malloc`` (for hosts without torch)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = c_vp()
+        ctx._check(lib().exabm4d_malloc(ctx.handle, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise ValueError("host array larger than device buffer")
+        self.ctx._check(lib().exabm4d_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data,
+                                                 arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("requested more bytes than the device buffer holds")
+        self.ctx._check(lib().exabm4d_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr,
+                                                 out.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._check(lib().exabm4d_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            lib().exabm4d_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One ``exabm4d_ctx`` -- bound to the process that created it and one device."""
+
+    def __init__(self, device=0):
+        self.pid = os.getpid()
+        self.device = int(device)
+        h = c_vp()
+        rc = lib().exabm4d_create(self.device, ctypes.byref(h))
+        if rc:
+            raise NativeError("exabm4d_create(device=%d) failed: %s" % (
+                self.device, lib().exabm4d_last_error(None).decode()))
+        self.handle = h
+
+    def _check(self, rc):
+        if rc:
+            msg = lib().exabm4d_last_error(self.handle).decode()
+            if rc in (-1, -2):
+                raise ValueError(msg)
+            raise NativeError(msg)
+
+    # -- memory ----------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, arr.nbytes).upload(arr)
+
+    def sync(self):
+        self._check(lib().exabm4d_sync(self.handle))
+
+    def set_option(self, name, value):
+        self._check(lib().exabm4d_set_option(self.handle, name.encode(), int(value)))
+
+    def set_stream(self, hip_stream):
+        self._check(lib().exabm4d_set_stream(self.handle, hip_stream))
+
+    # -- HIP events on the context's stream -------------------------------------------------
+    def event(self):
+        e = c_vp()
+        self._check(lib().exabm4d_event_create(self.handle, ctypes.byref(e)))
+        return e
+
+    def record(self, ev):
+        self._check(lib().exabm4d_event_record(self.handle, ev))
+
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        self._check(lib().exabm4d_event_elapsed_ms(self.handle, a, b, ctypes.byref(ms)))
+        return float(ms.value)
+
+    # -- BM4D ---------------------------------------------------------------------------------
+    def blockmatch(self, vol, shape, sigma, c_match, keys, params=None, batch=1):
+        p = params or default_params()
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_blockmatch_dev(self.handle, _ptr(vol), nz, ny, nx, batch,
+                                                 float(sigma), float(c_match), ctypes.byref(p),
+                                                 _ptr(keys)))
+
+    def stage(self, noisy, basic, keys, shape, sigma, num, den, params=None, batch=1):
+        p = params or default_params()
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_stage_dev(self.handle, _ptr(noisy), _ptr(basic), _ptr(keys), nz,
+                                            ny, nx, batch, float(sigma), ctypes.byref(p),
+                                            _ptr(num), _ptr(den)))
+
+    def normalize(self, num, den, out, n, clip=None):
+        lo, hi = (1.0, 0.0) if clip is None else clip
+        self._check(lib().exabm4d_normalize_dev(self.handle, _ptr(num), _ptr(den), _ptr(out), n,
+                                                float(lo), float(hi)))
+
+    def denoise_f32(self, src, dst, shape, sigma, params=None, stages=2, clip=None, batch=1):
+        p = params or default_params()
+        nz, ny, nx = shape
+        lo, hi = (1.0, 0.0) if clip is None else clip
+        self._check(lib().exabm4d_denoise_f32_dev(self.handle, _ptr(src), _ptr(dst), nz, ny, nx,
+                                                  batch, float(sigma), ctypes.byref(p),
+                                                  int(stages), float(lo), float(hi)))
+
+    def denoise_u16(self, src, dst, shape, sigma, offset, params=None, stages=2, batch=1):
+        p = params or default_params()
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_denoise_u16_dev(self.handle, _ptr(src), _ptr(dst), nz, ny, nx,
+                                                  batch, float(sigma), float(offset),
+                                                  ctypes.byref(p), int(stages)))
+
+    def denoise_f32_host(self, arr, sigma, params=None, stages=2, clip=None):
+        """numpy fp32 [N,]Z,Y,X in -> new numpy array out (H2D, kernels, D2H, sync)."""
+        p = params or default_params()
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if arr.ndim == 3:
+            batch, (nz, ny, nx) = 1, arr.shape
+        elif arr.ndim == 4:
+            batch, (nz, ny, nx) = arr.shape[0], arr.shape[1:]
+        else:
+            raise ValueError("expected a 3-D volume or a 4-D batch of volumes")
+        out = np.empty_like(arr)
+        lo, hi = (1.0, 0.0) if clip is None else clip
+        self._check(lib().exabm4d_denoise_f32_host(self.handle, arr.ctypes.data, out.ctypes.data,
+                                                   nz, ny, nx, batch, float(sigma),
+                                                   ctypes.byref(p), int(stages), float(lo),
+                                                   float(hi)))
+        return out
+
+    # -- transforms ---------------------------------------------------------------------------
+    def transform_forward(self, tf, src, dst, n, src_is_u16):
+        fn = (lib().exabm4d_transform_forward_u16_dev if src_is_u16
+              else lib().exabm4d_transform_forward_f32_dev)
+        self._check(fn(self.handle, ctypes.byref(tf), _ptr(src), _ptr(dst), n))
+
+    def transform_inverse(self, tf, src, dst, n, quantise=True):
+        fn = (lib().exabm4d_transform_inverse_u16_dev if quantise
+              else lib().exabm4d_transform_inverse_f32_dev)
+        self._check(fn(self.handle, ctypes.byref(tf), _ptr(src), _ptr(dst), n))
+
+    # -- tiling -------------------------------------------------------------------------------
+    def tile_gather(self, vol, shape, starts, patch, out):
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 3)
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_tile_gather_dev(
+            self.handle, _ptr(vol), nz, ny, nx, starts.ctypes.data_as(c_i32p), len(starts),
+            int(patch), _ptr(out)))
+
+    def tile_accumulate(self, preds, starts, patch, trim, acc, wgt, shape):
+        starts = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1, 3)
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_tile_accumulate_dev(
+            self.handle, _ptr(preds), starts.ctypes.data_as(c_i32p), len(starts), int(patch),
+            int(trim), _ptr(acc), _ptr(wgt), nz, ny, nx))
+
+    def tile_finalize(self, tf, acc, wgt, out, n):
+        self._check(lib().exabm4d_tile_finalize_u16_dev(self.handle, ctypes.byref(tf), _ptr(acc),
+                                                        _ptr(wgt), _ptr(out), n))
+
+    def close(self):
+        if self.handle and os.getpid() == self.pid:
+            lib().exabm4d_destroy(self.handle)
+        self.handle = None
+
+
+_contexts = {}
+_ctx_lock = threading.Lock()
+
+
+def context(device=None):
+    """The calling process's context for ``device`` (default: LOCAL_RANK or 0), created lazily.
+
+    A context inherited through fork() is never reused: HIP state does not survive fork."""
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    key = (os.getpid(), int(device))
+    with _ctx_lock:
+        ctx = _contexts.get(key)
+        if ctx is None:
+            ctx = Context(device)
+            _contexts[key] = ctx
+    return ctx
+
+
+def device_count():
+    return int(lib().exabm4d_device_count())
+
+
+# -- host-only helpers (no GPU) -----------------------------------------------------------------
+def grid_positions(n):
+    c = lib().exabm4d_grid_count(int(n))
+    pos = np.zeros(max(c, 0), dtype=np.int32)
+    if c > 0:
+        lib().exabm4d_grid_positions(int(n), pos.ctypes.data_as(c_i32p))
+    return pos
+
+
+def tables(params=None):
+    p = params or default_params()
+    dct = np.zeros(64, dtype=np.float32)
+    win = np.zeros(512, dtype=np.float32)
+    rc = lib().exabm4d_tables(ctypes.byref(p), dct.ctypes.data_as(c_f32p),
+                              win.ctypes.data_as(c_f32p))
+    if rc:
+        raise ValueError(lib().exabm4d_last_error(None).decode())
+    return dct.reshape(8, 8), win.reshape(8, 8, 8)
+
+
+def match_decode(keys16, ref_pos, ny, nx):
+    keys16 = np.ascontiguousarray(keys16, dtype=np.uint32)
+    idx = np.zeros(16, dtype=np.int64)
+    dist = np.zeros(16, dtype=np.float32)
+    cnt = ctypes.c_int()
+    rc = lib().exabm4d_match_decode(keys16.ctypes.data_as(c_u32p), int(ref_pos[0]),
+                                    int(ref_pos[1]), int(ref_pos[2]), int(ny), int(nx),
+                                    idx.ctypes.data_as(c_i64p), dist.ctypes.data_as(c_f32p),
+                                    ctypes.byref(cnt))
+    if rc:
+        raise ValueError(lib().exabm4d_last_error(None).decode())
+    return idx, dist, cnt.value

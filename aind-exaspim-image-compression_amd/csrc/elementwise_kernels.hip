@@ -1,0 +1,257 @@
+// elementwise_kernels.hip -- HBM-bound streams of the hot path:
+//   normalise (a-B6) + clip (a-C)                  data_handling.py:333
+//   u16 -> f32 - offset (a-A)                      data_handling.py:353-354
+//   intensity transforms forward / inverse (a-D/E) transforms.py:113-152, :223-285, :332-371, :398-411
+//   overlap-tile gather / accumulate / finalise    inference.py:81-116, :153-199
+// Checker: oracle/host_oracle.py (pinned by tests/golden/*.npz generated from the reference).
+//
+// fp32 rounding points follow numpy: every Python-float constant of the reference object is
+// rounded to fp32 where numpy rounds it (host side, TfDev below) and every array operation is one
+// fp32 operation here (-ffp-contract=off; no fused multiply-add).  arcsinh / sinh are evaluated in
+// fp64 and rounded once.
+#include "exabm4d_kernels.h"
+
+namespace exabm4d {
+
+
+__device__ __forceinline__ float tf_forward(const TfDev& t, float x) {
+    if (t.wrapped) x = x - t.woff;
+    if (t.kind == 0) {
+        const float u = (x - t.off) / t.scale;
+        const float a = (float)asinh((double)u);
+        return a / t.norm;
+    } else if (t.kind == 1) {
+        float arg = t.gain * (x - t.off);
+        arg = arg + t.c38g2;
+        arg = arg + t.rn2;
+        const float g = t.two_over_gain * sqrtf(fmaxf(arg, 0.0f));
+        return g / t.norm;
+    } else {
+        const float y = (x - t.mn) / t.fden;
+        return fminf(fmaxf(y, 0.0f), t.clip);
+    }
+}
+__device__ __forceinline__ float tf_inverse_float(const TfDev& t, float y) {
+    float c;
+    if (t.kind == 0) {
+        const float s = (float)sinh((double)(y * t.norm));
+        c = t.off + t.scale * s;
+    } else if (t.kind == 1) {
+        const float d = fmaxf(y, 0.0f) * t.norm;
+        const float h = d * t.gain / 2.0f;
+        const float arg = h * h;
+        const float u = (arg - t.cinvg2) - t.rn2;
+        c = t.off + u / t.gain;
+    } else {
+        c = y * t.range + t.mn;
+    }
+    if (t.wrapped) c = c + t.woff;
+    return c;
+}
+__device__ __forceinline__ uint16_t quantise_u16(float c, float maxc) {
+    c = fminf(fmaxf(c, 0.0f), maxc);     // np.clip(counts, 0, max_count)
+    return (uint16_t)rintf(c);           // np.rint (half-to-even) then astype(uint16)
+}
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 256 * 8;
+
+__global__ __launch_bounds__(EW_THREADS) void normalize_kernel(const float* __restrict__ num,
+                                                               const float* __restrict__ den,
+                                                               float* __restrict__ out, size_t n,
+                                                               float lo, float hi, int do_clip) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = num[i] / den[i];
+        if (do_clip) v = fminf(fmaxf(v, lo), hi);
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void counts_from_u16_kernel(const uint16_t* __restrict__ in,
+                                                                     float* __restrict__ out,
+                                                                     size_t n, float offset) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (float)in[i] - offset;
+}
+
+// out = rint(clip(num/den + offset, 0, 65535)) as uint16
+__global__ __launch_bounds__(EW_THREADS) void normalize_u16_kernel(const float* __restrict__ num,
+                                                                   const float* __restrict__ den,
+                                                                   uint16_t* __restrict__ out,
+                                                                   size_t n, float offset) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = num[i] / den[i] + offset;
+        out[i] = quantise_u16(v, 65535.0f);
+    }
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(EW_THREADS) void tf_forward_kernel(TfDev t, const TIn* __restrict__ in,
+                                                                float* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = tf_forward(t, (float)in[i]);
+}
+
+template <bool QUANT>
+__global__ __launch_bounds__(EW_THREADS) void tf_inverse_kernel(TfDev t, const float* __restrict__ in,
+                                                                void* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float c = tf_inverse_float(t, in[i]);
+        if (QUANT)
+            reinterpret_cast<uint16_t*>(out)[i] = quantise_u16(c, t.maxc);
+        else
+            reinterpret_cast<float*>(out)[i] = c;
+    }
+}
+
+// ---- overlap tiling ------------------------------------------------------------------------------
+struct PatchStarts {
+    int v[64 * 3];  // (z,y,x) of up to 64 patches, by value in the kernarg segment
+};
+
+__global__ __launch_bounds__(EW_THREADS) void tile_gather_kernel(const float* __restrict__ vol,
+                                                                 int nz, int ny, int nx,
+                                                                 PatchStarts st, int patch,
+                                                                 float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int sz0 = st.v[3 * b], sy0 = st.v[3 * b + 1], sx0 = st.v[3 * b + 2];
+    const size_t pv = (size_t)patch * patch * patch;
+    float* __restrict__ o = out + (size_t)b * pv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % patch), y = (int)((i / patch) % patch),
+                  z = (int)(i / ((size_t)patch * patch));
+        const int gz = sz0 + z, gy = sy0 + y, gx = sx0 + x;
+        float v = 0.0f;  // add_padding: zeros beyond the volume
+        if (gz < nz && gy < ny && gx < nx) v = vol[((size_t)gz * ny + gy) * nx + gx];
+        o[i] = v;
+    }
+}
+
+// One patch per launch: patches of one batch overlap, and the reference adds them one after the
+// other in patch order (inference.py:89-103).  Stream order reproduces exactly that order, so the
+// sums are bit-identical to the reference's and no atomics are needed.
+__global__ __launch_bounds__(EW_THREADS) void tile_accumulate_kernel(const float* __restrict__ pred,
+                                                                     int sz0, int sy0, int sx0,
+                                                                     int patch, int trim,
+                                                                     float* __restrict__ acc,
+                                                                     float* __restrict__ wgt,
+                                                                     int nz, int ny, int nx) {
+    const int core = patch - 2 * trim;
+    const size_t cv = (size_t)core * core * core;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % core), y = (int)((i / core) % core),
+                  z = (int)(i / ((size_t)core * core));
+        const int gz = sz0 + trim + z, gy = sy0 + trim + y, gx = sx0 + trim + x;
+        if (gz < nz && gy < ny && gx < nx) {
+            const size_t o = ((size_t)gz * ny + gy) * nx + gx;
+            const float p = pred[((size_t)(z + trim) * patch + (y + trim)) * patch + (x + trim)];
+            acc[o] = acc[o] + p;
+            wgt[o] = wgt[o] + 1.0f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void tile_finalize_kernel(TfDev t,
+                                                                   const float* __restrict__ acc,
+                                                                   const float* __restrict__ wgt,
+                                                                   uint16_t* __restrict__ out,
+                                                                   size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float w = wgt[i] + 1e-8f;      // accum_wgt += 1e-8
+        const float y = acc[i] / w;          // accum_pred /= accum_wgt
+        out[i] = quantise_u16(tf_inverse_float(t, y), t.maxc);
+    }
+}
+
+static inline unsigned ew_blocks(size_t n) {
+    size_t b = (n + EW_THREADS - 1) / EW_THREADS;
+    if (b > (size_t)EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+hipError_t launch_normalize(const float* num, const float* den, float* out, size_t n, float lo,
+                            float hi, hipStream_t s) {
+    hipLaunchKernelGGL(normalize_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, num, den, out,
+                       n, lo, hi, lo <= hi ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, float offset,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(counts_from_u16_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, in, out,
+                       n, offset);
+    return hipGetLastError();
+}
+hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,
+                                float offset, hipStream_t s) {
+    hipLaunchKernelGGL(normalize_u16_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, num, den,
+                       out, n, offset);
+    return hipGetLastError();
+}
+hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(tf_forward_kernel<uint16_t>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t,
+                       in, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_tf_forward_f32(const TfDev& t, const float* in, float* out, size_t n,
+                                 hipStream_t s) {
+    hipLaunchKernelGGL(tf_forward_kernel<float>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t, in,
+                       out, n);
+    return hipGetLastError();
+}
+hipError_t launch_tf_inverse(const TfDev& t, const float* in, void* out, size_t n, int quant,
+                             hipStream_t s) {
+    if (quant)
+        hipLaunchKernelGGL(tf_inverse_kernel<true>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t,
+                           in, out, n);
+    else
+        hipLaunchKernelGGL(tf_inverse_kernel<false>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t,
+                           in, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_tile_gather(const float* vol, int nz, int ny, int nx, const int* starts, int nb,
+                              int patch, float* out, hipStream_t s) {
+    const size_t pv = (size_t)patch * patch * patch;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int cnt = nb - b0 < 64 ? nb - b0 : 64;
+        PatchStarts st;
+        for (int i = 0; i < 3 * cnt; i++) st.v[i] = starts[3 * b0 + i];
+        dim3 grid(ew_blocks(pv) > 64 ? 64 : ew_blocks(pv), (unsigned)cnt);
+        hipLaunchKernelGGL(tile_gather_kernel, grid, dim3(EW_THREADS), 0, s, vol, nz, ny, nx, st,
+                           patch, out + (size_t)b0 * pv);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t launch_tile_accumulate(const float* preds, const int* starts, int nb, int patch, int trim,
+                                  float* acc, float* wgt, int nz, int ny, int nx, hipStream_t s) {
+    const size_t pv = (size_t)patch * patch * patch;
+    const int core = patch - 2 * trim;
+    const size_t cv = (size_t)core * core * core;
+    for (int b = 0; b < nb; b++) {
+        hipLaunchKernelGGL(tile_accumulate_kernel, dim3(ew_blocks(cv)), dim3(EW_THREADS), 0, s,
+                           preds + (size_t)b * pv, starts[3 * b], starts[3 * b + 1],
+                           starts[3 * b + 2], patch, trim, acc, wgt, nz, ny, nx);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t launch_tile_finalize(const TfDev& t, const float* acc, const float* wgt, uint16_t* out,
+                                size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(tile_finalize_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t, acc,
+                       wgt, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace exabm4d

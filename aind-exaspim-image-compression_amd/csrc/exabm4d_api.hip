@@ -1,0 +1,580 @@
+// exabm4d_api.hip -- the C-ABI of libexabm4d.so (include/exabm4d.h): context, scratch, tables,
+// argument checking and the launch sequences.  Host code only; kernels live in *_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/exabm4d.h"
+#include "exabm4d_kernels.h"
+
+
+using namespace exabm4d;
+
+struct exabm4d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float dct[64];
+    float win[512];
+    float* win_dev = nullptr;
+    double win_beta = -1.0;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+static int fail(exabm4d_ctx* ctx, int code, const std::string& msg) {
+    g_err = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+static int fail_hip(exabm4d_ctx* ctx, hipError_t e, const char* what) {
+    return fail(ctx, EXABM4D_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, expr)                                         \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return fail_hip((ctx), _e, #expr);   \
+    } while (0)
+
+// ---- tables -----------------------------------------------------------------
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0, q = x * x / 4.0;
+    for (int k = 1; k < 200; k++) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+static void make_tables(double beta, float* dct64, float* win512) {
+    const double pi = 3.14159265358979323846;
+    for (int u = 0; u < 8; u++)
+        for (int n = 0; n < 8; n++) {
+            const double c = (u == 0) ? std::sqrt(1.0 / 8.0) : std::sqrt(2.0 / 8.0);
+            dct64[u * 8 + n] = (float)(c * std::cos(pi * (2.0 * n + 1.0) * u / 16.0));
+        }
+    double k[8];
+    for (int n = 0; n < 8; n++) {
+        if (beta == 0.0) {
+            k[n] = 1.0;
+        } else {
+            const double r = 2.0 * n / 7.0 - 1.0;
+            k[n] = bessel_i0(beta * std::sqrt(1.0 - r * r)) / bessel_i0(beta);
+        }
+    }
+    for (int z = 0; z < 8; z++)
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) win512[(z * 8 + y) * 8 + x] = (float)(k[z] * k[y] * k[x]);
+}
+
+static int check_params(exabm4d_ctx* ctx, const exabm4d_params* p) {
+    if (!p) return fail(ctx, EXABM4D_ERR_INVALID, "params is NULL");
+    if (p->size != sizeof(exabm4d_params))
+        return fail(ctx, EXABM4D_ERR_INVALID, "params.size does not match this library");
+    if (p->block != 8 || p->step != 4 || p->search != 11 || p->max_group != 16)
+        return fail(ctx, EXABM4D_ERR_UNSUPPORTED,
+                    "only block=8, step=4, search=11, max_group=16 are implemented");
+    if (!(p->lambda_ht >= 0.0f) || !(p->c_match_ht > 0.0f) || !(p->c_match_wie > 0.0f) ||
+        !(p->kaiser_beta >= 0.0f))
+        return fail(ctx, EXABM4D_ERR_INVALID, "params: thresholds must be positive, beta >= 0");
+    return EXABM4D_OK;
+}
+static int make_geom(exabm4d_ctx* ctx, int nz, int ny, int nx, int batch, VolGeom& g) {
+    if (nz < 8 || ny < 8 || nx < 8) return fail(ctx, EXABM4D_ERR_INVALID, "every volume axis must be >= 8");
+    if (batch < 1 || batch > 65535) return fail(ctx, EXABM4D_ERR_INVALID, "batch must be in [1, 65535]");
+    g.nz = nz; g.ny = ny; g.nx = nx;
+    g.gz = grid_count(nz); g.gy = grid_count(ny); g.gx = grid_count(nx);
+    g.az = aligned_count(nz); g.ay = aligned_count(ny); g.ax = aligned_count(nx);
+    g.nvox = (long long)nz * ny * nx;
+    g.nref = (long long)g.gz * g.gy * g.gx;
+    if (g.nref > 0x7FFFFFFFLL) return fail(ctx, EXABM4D_ERR_INVALID, "volume too large for one launch");
+    return EXABM4D_OK;
+}
+static uint32_t keymax_of(float sigma, float c_match) {
+    const float tau512 = (float)((double)c_match * (double)sigma * (double)sigma * 512.0);
+    uint32_t u;
+    std::memcpy(&u, &tau512, 4);
+    return (u & KEY_DMASK) + 0x800u;
+}
+static int ensure_window(exabm4d_ctx* ctx, double beta) {
+    if (ctx->win_dev && ctx->win_beta == beta) return EXABM4D_OK;
+    make_tables(beta, ctx->dct, ctx->win);
+    if (!ctx->win_dev) HIP_TRY(ctx, hipMalloc((void**)&ctx->win_dev, sizeof(float) * 512));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->win_dev, ctx->win, sizeof(float) * 512, hipMemcpyHostToDevice));
+    ctx->win_beta = beta;
+    return EXABM4D_OK;
+}
+static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return EXABM4D_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, bytes);
+    if (e != hipSuccess) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "device scratch allocation of %zu bytes failed: %s", bytes,
+                      hipGetErrorString(e));
+        return fail(ctx, EXABM4D_ERR_NOMEM, msg);
+    }
+    ctx->scratch_bytes = bytes;
+    return EXABM4D_OK;
+}
+static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static int make_tfdev(exabm4d_ctx* ctx, const exabm4d_transform* t, TfDev& d) {
+    if (!t) return fail(ctx, EXABM4D_ERR_INVALID, "transform is NULL");
+    if (t->size != sizeof(exabm4d_transform))
+        return fail(ctx, EXABM4D_ERR_INVALID, "transform.size does not match this library");
+    if (t->kind < 0 || t->kind > 2) return fail(ctx, EXABM4D_ERR_INVALID, "unknown transform kind");
+    std::memset(&d, 0, sizeof d);
+    d.kind = t->kind;
+    d.wrapped = t->wrapped ? 1 : 0;
+    d.woff = (float)t->wrap_offset;
+    d.maxc = (float)t->max_count;
+    d.off = (float)t->offset;
+    d.scale = (float)t->scale;
+    d.norm = (float)t->norm;
+    d.gain = (float)t->gain;
+    d.c38g2 = (float)((3.0 / 8.0) * t->gain * t->gain);
+    d.rn2 = (float)(t->read_noise * t->read_noise);
+    d.two_over_gain = (float)(2.0 / t->gain);
+    d.cinvg2 = (float)(t->c_inv * t->gain * t->gain);
+    d.mn = (float)t->mn;
+    d.fden = (float)(t->mx - t->mn + 1e-8);
+    d.clip = (float)t->clip;
+    d.range = (float)(t->mx - t->mn);
+    return EXABM4D_OK;
+}
+
+extern "C" {
+
+int exabm4d_version(void) { return EXABM4D_VERSION; }
+
+const char* exabm4d_last_error(const exabm4d_ctx* ctx) {
+    if (ctx && !ctx->err.empty()) return ctx->err.c_str();
+    return g_err.c_str();
+}
+
+int exabm4d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int exabm4d_create(int device, exabm4d_ctx** out) {
+    if (!out) return fail(nullptr, EXABM4D_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, EXABM4D_ERR_NODEVICE, "no HIP device visible (libexabm4d needs a gfx950 GPU)");
+    if (device < 0 || device >= n) return fail(nullptr, EXABM4D_ERR_INVALID, "device index out of range");
+    HIP_TRY(nullptr, hipSetDevice(device));
+    exabm4d_ctx* ctx = new (std::nothrow) exabm4d_ctx();
+    if (!ctx) return fail(nullptr, EXABM4D_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail_hip(nullptr, e, "hipStreamCreate");
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return EXABM4D_OK;
+}
+
+int exabm4d_destroy(exabm4d_ctx* ctx) {
+    if (!ctx) return EXABM4D_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->win_dev) (void)hipFree(ctx->win_dev);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return EXABM4D_OK;
+}
+
+int exabm4d_set_stream(exabm4d_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return EXABM4D_OK;
+}
+
+int exabm4d_sync(exabm4d_ctx* ctx) {
+    if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EXABM4D_OK;
+}
+
+int exabm4d_default_params(exabm4d_params* p) {
+    if (!p) return fail(nullptr, EXABM4D_ERR_INVALID, "params is NULL");
+    p->size = sizeof(exabm4d_params);
+    p->block = 8;
+    p->step = 4;
+    p->search = 11;
+    p->max_group = 16;
+    p->lambda_ht = 2.7f;
+    p->c_match_ht = 3.0f;
+    p->c_match_wie = 0.6f;
+    p->kaiser_beta = 2.0f;
+    return EXABM4D_OK;
+}
+
+int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (std::strcmp(name, "force_generic_bm") == 0) {
+        ctx->force_generic_bm = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
+    return fail(ctx, EXABM4D_ERR_INVALID, std::string("unknown option: ") + name);
+}
+
+// ---- memory helpers --------------------------------------------------------------------------------
+int exabm4d_malloc(exabm4d_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    *dptr = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(ctx, EXABM4D_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return EXABM4D_OK;
+}
+int exabm4d_free(exabm4d_ctx* ctx, void* dptr) {
+    if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
+    if (dptr) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(dptr));
+    }
+    return EXABM4D_OK;
+}
+int exabm4d_memcpy_h2d(exabm4d_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_memcpy_d2h(exabm4d_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_memset(exabm4d_ctx* ctx, void* dst, int value, size_t bytes) {
+    if (!ctx || (!dst && bytes)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_event_create(exabm4d_ctx* ctx, void** ev) {
+    if (!ctx || !ev) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    hipEvent_t e;
+    HIP_TRY(ctx, hipEventCreate(&e));
+    *ev = (void*)e;
+    return EXABM4D_OK;
+}
+int exabm4d_event_destroy(exabm4d_ctx* ctx, void* ev) {
+    if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
+    if (ev) HIP_TRY(ctx, hipEventDestroy((hipEvent_t)ev));
+    return EXABM4D_OK;
+}
+int exabm4d_event_record(exabm4d_ctx* ctx, void* ev) {
+    if (!ctx || !ev) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_event_elapsed_ms(exabm4d_ctx* ctx, void* a, void* b, float* ms) {
+    if (!ctx || !a || !b || !ms) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipEventSynchronize((hipEvent_t)b));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return EXABM4D_OK;
+}
+
+// ---- geometry + tables --------------------------------------------------------------------------------
+int exabm4d_grid_count(int n) { return grid_count(n); }
+int exabm4d_grid_positions(int n, int32_t* pos) {
+    if (!pos) return fail(nullptr, EXABM4D_ERR_INVALID, "pos is NULL");
+    const int c = grid_count(n), a = aligned_count(n);
+    for (int i = 0; i < c; i++) pos[i] = grid_pos(i, a, n);
+    return EXABM4D_OK;
+}
+int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512) {
+    int rc = check_params(nullptr, p);
+    if (rc) return rc;
+    if (!dct64 || !win512) return fail(nullptr, EXABM4D_ERR_INVALID, "NULL argument");
+    make_tables((double)p->kaiser_beta, dct64, win512);
+    return EXABM4D_OK;
+}
+size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages) {
+    if (nz < 8 || ny < 8 || nx < 8 || batch < 1) return 0;
+    const size_t n = (size_t)nz * ny * nx * (size_t)batch;
+    const size_t nref = (size_t)grid_count(nz) * grid_count(ny) * grid_count(nx) * (size_t)batch;
+    size_t b = align256(nref * MAXG * sizeof(uint32_t)) + 2 * align256(n * sizeof(float));
+    if (stages >= 2) b += align256(n * sizeof(float));
+    return b;
+}
+
+// ---- staged entry points ---------------------------------------------------------------------------------
+int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, int nx, int batch,
+                           float sigma, float c_match, const exabm4d_params* p, uint32_t* keys) {
+    if (!ctx || !vol || !keys) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!(sigma > 0.0f) || !(c_match > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma and c_match must be > 0");
+    VolGeom g;
+    rc = make_geom(ctx, nz, ny, nx, batch, g);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_blockmatch(vol, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
+                                   ctx->force_generic_bm));
+    return EXABM4D_OK;
+}
+
+int exabm4d_match_decode(const uint32_t* keys16, int rz, int ry, int rx, int ny, int nx,
+                         int64_t* idx, float* dist, int* count) {
+    if (!keys16 || !idx || !dist || !count) return fail(nullptr, EXABM4D_ERR_INVALID, "NULL argument");
+    int c = 0;
+    for (int k = 0; k < MAXG; k++) {
+        const uint32_t key = keys16[k];
+        if (key == KEY_EMPTY) {
+            idx[k] = -1;
+            dist[k] = INFINITY;
+            continue;
+        }
+        int dz, dy, dx;
+        code_to_disp(key & KEY_CMASK, dz, dy, dx);
+        idx[k] = ((int64_t)(rz + dz) * ny + (ry + dy)) * nx + (rx + dx);
+        const uint32_t sb = key & KEY_DMASK;
+        float s;
+        std::memcpy(&s, &sb, 4);
+        dist[k] = s / 512.0f;
+        c++;
+    }
+    *count = c;
+    return EXABM4D_OK;
+}
+
+int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
+                      const uint32_t* keys, int nz, int ny, int nx, int batch, float sigma,
+                      const exabm4d_params* p, float* num, float* den) {
+    if (!ctx || !noisy || !keys || !num || !den) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!(sigma > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma must be > 0");
+    VolGeom g;
+    rc = make_geom(ctx, nz, ny, nx, batch, g);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = ensure_window(ctx, (double)p->kaiser_beta);
+    if (rc) return rc;
+    const float thr = (float)((double)p->lambda_ht * (double)sigma);
+    const float sigma2 = (float)((double)sigma * (double)sigma);
+    HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, num,
+                              den, ctx->stream));
+    return EXABM4D_OK;
+}
+
+int exabm4d_normalize_dev(exabm4d_ctx* ctx, const float* num, const float* den, float* out,
+                          size_t n, float clip_lo, float clip_hi) {
+    if (!ctx || !num || !den || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_normalize(num, den, out, n, clip_lo, clip_hi, ctx->stream));
+    return EXABM4D_OK;
+}
+
+// ---- whole pipeline -----------------------------------------------------------------------------------------
+// noisy: fp32 counts on device.  Exactly one of out_f32 / out_u16 is written.
+static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, uint16_t* out_u16,
+                        const VolGeom& g, int batch, float sigma, const exabm4d_params* p,
+                        int stages, float clip_lo, float clip_hi, float u16_offset, char* scratch) {
+    const size_t n = (size_t)g.nvox * (size_t)batch;
+    uint32_t* keys = reinterpret_cast<uint32_t*>(scratch);
+    scratch += align256((size_t)g.nref * (size_t)batch * MAXG * sizeof(uint32_t));
+    float* num = reinterpret_cast<float*>(scratch);
+    scratch += align256(n * sizeof(float));
+    float* den = reinterpret_cast<float*>(scratch);
+    scratch += align256(n * sizeof(float));
+    float* basic = reinterpret_cast<float*>(scratch);  // only touched when stages >= 2
+
+    const float thr = (float)((double)p->lambda_ht * (double)sigma);
+    const float sigma2 = (float)((double)sigma * (double)sigma);
+    hipStream_t s = ctx->stream;
+
+    HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
+    HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+    HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
+                                   ctx->force_generic_bm));
+    HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2,
+                              num, den, s));
+    if (stages >= 2) {
+        HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
+        HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
+        HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+        HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys, s,
+                                       ctx->force_generic_bm));
+        HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2,
+                                  num, den, s));
+    }
+    if (out_u16)
+        HIP_TRY(ctx, launch_normalize_u16(num, den, out_u16, n, u16_offset, s));
+    else
+        HIP_TRY(ctx, launch_normalize(num, den, out_f32, n, clip_lo, clip_hi, s));
+    return EXABM4D_OK;
+}
+
+static int pipeline_checks(exabm4d_ctx* ctx, const void* in, const void* out, int nz, int ny, int nx,
+                           int batch, float sigma, const exabm4d_params* p, int stages, VolGeom& g) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!(sigma > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma must be > 0");
+    if (stages != 1 && stages != 2) return fail(ctx, EXABM4D_ERR_INVALID, "stages must be 1 or 2");
+    rc = make_geom(ctx, nz, ny, nx, batch, g);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ensure_window(ctx, (double)p->kaiser_beta);
+}
+
+int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
+                            int batch, float sigma, const exabm4d_params* p, int stages,
+                            float clip_lo, float clip_hi) {
+    VolGeom g;
+    int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
+    if (rc) return rc;
+    rc = ensure_scratch(ctx, exabm4d_scratch_bytes(nz, ny, nx, batch, stages));
+    if (rc) return rc;
+    return run_pipeline(ctx, in, out, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
+                        static_cast<char*>(ctx->scratch));
+}
+
+int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
+                            int nx, int batch, float sigma, float offset, const exabm4d_params* p,
+                            int stages) {
+    VolGeom g;
+    int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
+    if (rc) return rc;
+    const size_t n = (size_t)g.nvox * (size_t)batch;
+    const size_t base = exabm4d_scratch_bytes(nz, ny, nx, batch, stages);
+    rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+    if (rc) return rc;
+    char* scratch = static_cast<char*>(ctx->scratch);
+    float* noisy = reinterpret_cast<float*>(scratch + base);
+    HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream));
+    return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
+                        scratch);
+}
+
+int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
+                             int batch, float sigma, const exabm4d_params* p, int stages,
+                             float clip_lo, float clip_hi) {
+    VolGeom g;
+    int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
+    if (rc) return rc;
+    const size_t n = (size_t)g.nvox * (size_t)batch;
+    const size_t base = exabm4d_scratch_bytes(nz, ny, nx, batch, stages);
+    rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+    if (rc) return rc;
+    char* scratch = static_cast<char*>(ctx->scratch);
+    float* vol = reinterpret_cast<float*>(scratch + base);
+    HIP_TRY(ctx, hipMemcpyAsync(vol, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
+                      scratch);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EXABM4D_OK;
+}
+
+// ---- intensity transforms ---------------------------------------------------------------------------------
+int exabm4d_transform_forward_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const uint16_t* in, float* out, size_t n) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    TfDev d;
+    int rc = make_tfdev(ctx, t, d);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tf_forward_u16(d, in, out, n, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_transform_forward_f32_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const float* in, float* out, size_t n) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    TfDev d;
+    int rc = make_tfdev(ctx, t, d);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tf_forward_f32(d, in, out, n, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_transform_inverse_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const float* in, uint16_t* out, size_t n) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    TfDev d;
+    int rc = make_tfdev(ctx, t, d);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tf_inverse(d, in, out, n, 1, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_transform_inverse_f32_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const float* in, float* out, size_t n) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    TfDev d;
+    int rc = make_tfdev(ctx, t, d);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tf_inverse(d, in, out, n, 0, ctx->stream));
+    return EXABM4D_OK;
+}
+
+// ---- overlap tiling ---------------------------------------------------------------------------------------------
+int exabm4d_tile_gather_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, int nx,
+                            const int32_t* starts, int nb, int patch, float* out) {
+    if (!ctx || !vol || !starts || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (nb < 0 || patch < 1 || nz < 1 || ny < 1 || nx < 1) return fail(ctx, EXABM4D_ERR_INVALID, "bad sizes");
+    for (int i = 0; i < 3 * nb; i++)
+        if (starts[i] < 0) return fail(ctx, EXABM4D_ERR_INVALID, "negative patch start");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tile_gather(vol, nz, ny, nx, starts, nb, patch, out, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_tile_accumulate_dev(exabm4d_ctx* ctx, const float* preds, const int32_t* starts, int nb,
+                                int patch, int trim, float* accum_pred, float* accum_wgt, int nz,
+                                int ny, int nx) {
+    if (!ctx || !preds || !starts || !accum_pred || !accum_wgt)
+        return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (nb < 0 || patch < 1 || trim < 0 || 2 * trim >= patch) return fail(ctx, EXABM4D_ERR_INVALID, "bad sizes");
+    for (int i = 0; i < 3 * nb; i++)
+        if (starts[i] < 0) return fail(ctx, EXABM4D_ERR_INVALID, "negative patch start");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tile_accumulate(preds, starts, nb, patch, trim, accum_pred, accum_wgt, nz, ny,
+                                        nx, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_tile_finalize_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                  const float* accum_pred, const float* accum_wgt, uint16_t* out,
+                                  size_t n) {
+    if (!ctx || !accum_pred || !accum_wgt || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    TfDev d;
+    int rc = make_tfdev(ctx, t, d);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_tile_finalize(d, accum_pred, accum_wgt, out, n, ctx->stream));
+    return EXABM4D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// exabm4d_common.h -- constants and small device helpers shared by the gfx950 kernels.
+// The algorithm these kernels implement is frozen in DESIGN.md section 3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace exabm4d {
+
+constexpr int BLK = 8;          // cubic block edge
+constexpr int BVOX = 512;       // voxels per block
+constexpr int STEP = 4;         // reference grid step == cell edge
+constexpr int RAD = 5;          // search radius
+constexpr int SWIN = 11;        // search window edge
+constexpr int NCAND = 1331;     // SWIN^3
+constexpr int MAXG = 16;        // blocks per group
+constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t KEY_DMASK = 0xFFFFF800u;  // distance bits of a match key
+constexpr uint32_t KEY_CMASK = 0x000007FFu;  // displacement code bits
+
+// Geometry of one volume and its reference grid (host fills it; passed by value to kernels).
+struct VolGeom {
+    int nz, ny, nx;          // voxels
+    int gz, gy, gx;          // reference-grid points per axis (aligned + optional clamped last)
+    int az, ay, ax;          // aligned reference positions per axis: 4*i, i < a*
+    long long nvox;          // nz*ny*nx
+    long long nref;          // gz*gy*gx
+};
+
+__host__ __device__ inline int grid_count(int n) {
+    if (n < BLK) return 0;
+    int c = (n - BLK) / STEP + 1;
+    if ((n - BLK) % STEP) c++;
+    return c;
+}
+__host__ __device__ inline int aligned_count(int n) { return n < BLK ? 0 : (n - BLK) / STEP + 1; }
+// voxel position of grid point i along an axis of n voxels with a aligned points
+__host__ __device__ inline int grid_pos(int i, int a, int n) { return i < a ? STEP * i : n - BLK; }
+
+__host__ __device__ inline uint32_t disp_code(int dz, int dy, int dx) {
+    if (dz == 0 && dy == 0 && dx == 0) return 0u;
+    return 1u + (uint32_t)(((dz + RAD) * SWIN + (dy + RAD)) * SWIN + (dx + RAD));
+}
+__host__ __device__ inline void code_to_disp(uint32_t code, int& dz, int& dy, int& dx) {
+    if (code == 0) {
+        dz = dy = dx = 0;
+        return;
+    }
+    uint32_t l = code - 1;
+    dx = (int)(l % SWIN) - RAD;
+    dy = (int)((l / SWIN) % SWIN) - RAD;
+    dz = (int)(l / (SWIN * SWIN)) - RAD;
+}
+
+// Sorted (ascending) insertion of `key` into a 16-entry register list, dropping the largest.
+// Keys are unique, so min/max alone keep the list sorted.
+__device__ __forceinline__ void list_insert(uint32_t (&list)[MAXG], uint32_t key) {
+#pragma unroll
+    for (int k = 0; k < MAXG; k++) {
+        uint32_t lo = min(list[k], key);
+        key = max(list[k], key);
+        list[k] = lo;
+    }
+}
+
+}  // namespace exabm4d

@@ -1,0 +1,43 @@
+// exabm4d_kernels.h -- host-side launcher interface between exabm4d_api.hip and *_kernels.hip.
+#pragma once
+#include "exabm4d_common.h"
+
+namespace exabm4d {
+
+// Intensity-transform constants, already rounded to fp32 exactly where numpy rounds the
+// reference object's Python floats (machine_learning/transforms.py).
+struct TfDev {
+    int kind;     // 0 asinh, 1 anscombe, 2 linear
+    int wrapped;  // OffsetTransform wrapper
+    float woff;   // wrapper offset
+    float maxc;   // max_count
+    float off, scale, norm;                           // asinh (off/norm shared with anscombe)
+    float gain, c38g2, rn2, two_over_gain, cinvg2;    // anscombe
+    float mn, fden, clip, range;                      // linear: mn, mx-mn+1e-8, clip, mx-mn
+};
+
+hipError_t launch_normalize(const float* num, const float* den, float* out, size_t n, float lo,
+                            float hi, hipStream_t s);
+hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, float offset,
+                                  hipStream_t s);
+hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,
+                                float offset, hipStream_t s);
+hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,
+                                 hipStream_t s);
+hipError_t launch_tf_forward_f32(const TfDev& t, const float* in, float* out, size_t n,
+                                 hipStream_t s);
+hipError_t launch_tf_inverse(const TfDev& t, const float* in, void* out, size_t n, int quant,
+                             hipStream_t s);
+hipError_t launch_tile_gather(const float* vol, int nz, int ny, int nx, const int* starts, int nb,
+                              int patch, float* out, hipStream_t s);
+hipError_t launch_tile_accumulate(const float* preds, const int* starts, int nb, int patch, int trim,
+                                  float* acc, float* wgt, int nz, int ny, int nx, hipStream_t s);
+hipError_t launch_tile_finalize(const TfDev& t, const float* acc, const float* wgt, uint16_t* out,
+                                size_t n, hipStream_t s);
+hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
+                             uint32_t* keys, hipStream_t stream, int force_generic);
+hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
+                        const VolGeom& g, int batch, const float* dct64, const float* win_dev,
+                        float thr, float sigma2, float* num, float* den, hipStream_t stream);
+
+}  // namespace exabm4d

@@ -1,0 +1,200 @@
+/*
+ * exabm4d.h -- C-ABI of libexabm4d.so (MI355X / gfx950 native BM4D denoise + intensity
+ * transform + overlap-tile stitching hot path for ExaSPIM uint16 volumes).
+ *
+ * This is the drop-in boundary for the hot path of
+ * AllenNeuralDynamics/aind-exaspim-image-compression.  The reference is pure Python; the
+ * arithmetic on its hot path is reached through these interfaces, each of which one entry
+ * point below replaces (paths relative to the reference checkout, src/aind_exaspim_image_compression/):
+ *
+ *   bm4d(raw, sigma)                      machine_learning/data_handling.py:332, :926 ; evaluate.py:202
+ *   np.clip(teacher, 0, max_count)        machine_learning/data_handling.py:333, :927
+ *   read_counts (u16 -> f32 - offset)     machine_learning/data_handling.py:337-354
+ *   IntensityTransform.forward            machine_learning/transforms.py:113-129, :244-259, :332-348, :398-401
+ *   IntensityTransform.inverse[_float]    machine_learning/transforms.py:131-152, :261-285, :350-371, :403-411
+ *   predict(): patch gather / pad         inference.py:153-174, :178-199, :202-226
+ *   predict(): accumulate / normalise     inference.py:81-116
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, POD structs whose first field is their own sizeof
+ *     (ABI evolution).  No allocation is returned across the ABI except through
+ *     exabm4d_malloc/exabm4d_free (thin hipMalloc wrappers for hosts without a device
+ *     allocator of their own).
+ *   - Every function returns 0 on success or a negative exabm4d_status; a message is available
+ *     from exabm4d_last_error().  No C++ exception crosses the boundary.
+ *   - "_dev" functions take DEVICE pointers and enqueue on the context's stream without
+ *     synchronising; "_host" functions take HOST pointers, copy in/out and synchronise.
+ *   - Volumes are C-contiguous [z][y][x]; a batch is `batch` such volumes back to back.
+ *   - A context belongs to one (process, device); create it after fork(), never before
+ *     (the reference calls bm4d from forked ProcessPoolExecutor workers, scripts/precompute.py:215).
+ *   - The BM4D algorithm is the specification frozen in DESIGN.md section 3 (the reference's
+ *     own BM4D is the closed third-party wheel bm4d==4.2.5, uv.lock:387-400; parity with it is
+ *     unpinned -- see DESIGN.md).
+ */
+#ifndef EXABM4D_H
+#define EXABM4D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXABM4D_VERSION 100 /* 0.1.0 */
+
+typedef enum exabm4d_status {
+    EXABM4D_OK = 0,
+    EXABM4D_ERR_INVALID = -1,     /* bad argument (NULL pointer, dims < 8, bad struct size ...) */
+    EXABM4D_ERR_UNSUPPORTED = -2, /* profile value outside what the kernels implement          */
+    EXABM4D_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString)  */
+    EXABM4D_ERR_NOMEM = -4,       /* device scratch allocation failed                            */
+    EXABM4D_ERR_NODEVICE = -5     /* no usable gfx950 device                                     */
+} exabm4d_status;
+
+/* BM4D profile.  Defaults (exabm4d_default_params) are BASELINE.json's parameter contract:
+ * block 8^3, step 4, search window 11^3, groups of <= 16, 3-D DCT + Haar, lambda 2.7. */
+typedef struct exabm4d_params {
+    uint32_t size;        /* = sizeof(exabm4d_params)                                    */
+    int32_t block;        /* cubic block edge; only 8 is implemented                      */
+    int32_t step;         /* reference-block grid step; only 4                            */
+    int32_t search;       /* search window edge (displacements -5..5); only 11            */
+    int32_t max_group;    /* blocks per group, power of two <= 16; only 16               */
+    float lambda_ht;      /* hard threshold = lambda_ht * sigma                           */
+    float c_match_ht;     /* stage-1 match threshold: mean sq. diff <= c_match_ht*sigma^2 */
+    float c_match_wie;    /* stage-2 match threshold (on the basic estimate)              */
+    float kaiser_beta;    /* aggregation window, separable Kaiser(8, beta); 0 => all ones */
+} exabm4d_params;
+
+/* Intensity transform descriptor (machine_learning/transforms.py).  `kind` selects the base
+ * transform; `wrapped` != 0 composes OffsetTransform(base, wrap_offset) around it
+ * (transforms.py:374-411).  All parameters are the Python floats of the reference object;
+ * the kernels round them to fp32 exactly where numpy does. */
+enum { EXABM4D_TF_ASINH = 0, EXABM4D_TF_ANSCOMBE = 1, EXABM4D_TF_LINEAR = 2 };
+typedef struct exabm4d_transform {
+    uint32_t size;        /* = sizeof(exabm4d_transform) */
+    int32_t kind;         /* EXABM4D_TF_*                */
+    int32_t wrapped;      /* 0/1: OffsetTransform wrapper */
+    int32_t reserved;
+    double wrap_offset;   /* OffsetTransform.offset       */
+    double max_count;     /* clamp of inverse(); for a wrapper: base.max_count */
+    double offset;        /* asinh.offset / anscombe.offset                    */
+    double scale;         /* asinh.scale                                        */
+    double norm;          /* asinh._norm / anscombe._norm (python float)        */
+    double gain;          /* anscombe.gain                                      */
+    double read_noise;    /* anscombe.read_noise                                */
+    double c_inv;         /* anscombe._c_inv (1/8 or 3/8)                       */
+    double mn, mx, clip;  /* linear                                             */
+} exabm4d_transform;
+
+typedef struct exabm4d_ctx exabm4d_ctx;
+
+/* ---- library / context ------------------------------------------------------------------ */
+int exabm4d_version(void);
+/* Message of the last failing call on this thread (ctx may be NULL). Never NULL. */
+const char* exabm4d_last_error(const exabm4d_ctx* ctx);
+/* Number of HIP devices visible (no context needed; does not initialise a device). */
+int exabm4d_device_count(void);
+int exabm4d_create(int device, exabm4d_ctx** out);
+int exabm4d_destroy(exabm4d_ctx* ctx);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+int exabm4d_set_stream(exabm4d_ctx* ctx, void* hip_stream);
+int exabm4d_sync(exabm4d_ctx* ctx);
+int exabm4d_default_params(exabm4d_params* p);
+/* Diagnostic switches. "force_generic_bm" = 1 routes every reference block through the
+ * one-wave-per-block matching kernel (normally used only for grid points that are not a
+ * multiple of 4); the parity tests use it to check the two kernels against each other. */
+int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
+
+/* ---- device memory helpers (for ctypes hosts without torch) ------------------------------ */
+int exabm4d_malloc(exabm4d_ctx* ctx, size_t bytes, void** dptr);
+int exabm4d_free(exabm4d_ctx* ctx, void* dptr);
+int exabm4d_memcpy_h2d(exabm4d_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int exabm4d_memcpy_d2h(exabm4d_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int exabm4d_memset(exabm4d_ctx* ctx, void* dst_dev, int value, size_t bytes);
+/* HIP-event timing on the context's stream (bench.py measures kernels with these, not with
+ * torch events, so the timing is on the stream the kernels are launched on). */
+int exabm4d_event_create(exabm4d_ctx* ctx, void** ev);
+int exabm4d_event_destroy(exabm4d_ctx* ctx, void* ev);
+int exabm4d_event_record(exabm4d_ctx* ctx, void* ev);
+int exabm4d_event_elapsed_ms(exabm4d_ctx* ctx, void* ev_start, void* ev_stop, float* ms);
+
+/* ---- geometry + tables (host, no device) -------------------------------------------------- */
+/* Reference-block grid along an axis of n voxels: 0,4,8,... plus n-8 when (n-8)%4 != 0. */
+int exabm4d_grid_count(int n);
+int exabm4d_grid_positions(int n, int32_t* pos);
+/* The constant tables the kernels use: orthonormal DCT-II 8x8 (row u, col n) and the 8^3
+ * aggregation window (z,y,x raster). Computed in double, rounded once to fp32. */
+int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512);
+/* Bytes of device scratch a denoise call of this shape needs (match table + num/den + basic). */
+size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages);
+
+/* ---- BM4D staged entry points (parity hooks; a-B1 .. a-B6 of SURVEY.md section 8) ---------- */
+/* Block matching.  keys: [batch][nref][16] uint32, nref = gz*gy*gx in (z,y,x) raster of the
+ * reference grid.  key = (bits(S) & 0xFFFFF800) | code, S = block SSD (fp32),
+ * code = 0 for the reference block itself else 1 + ((dz+5)*11 + (dy+5))*11 + (dx+5).
+ * Sorted ascending; unused slots 0xFFFFFFFF.  c_match: threshold factor (c_match*sigma^2). */
+int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, int nx, int batch,
+                           float sigma, float c_match, const exabm4d_params* p, uint32_t* keys);
+/* Host decode of one reference's 16 keys at grid position (rz,ry,rx) [voxels]:
+ * idx[k] = linear voxel offset of the matched block corner, dist[k] = quantised S/512,
+ * *count = number of valid entries (group size is the largest power of two <= count). */
+int exabm4d_match_decode(const uint32_t* keys16, int rz, int ry, int rx, int ny, int nx,
+                         int64_t* idx, float* dist, int* count);
+/* Collaborative filtering + aggregation.  basic == NULL: hard-threshold stage on `noisy`;
+ * basic != NULL: Wiener stage (groups of `noisy` and `basic` at the same positions).
+ * num/den ([batch][nz][ny][nx] fp32) are ADDED to; zero them first (exabm4d_memset). */
+int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
+                      const uint32_t* keys, int nz, int ny, int nx, int batch, float sigma,
+                      const exabm4d_params* p, float* num, float* den);
+/* out = num/den, then clamp to [clip_lo, clip_hi] when clip_lo <= clip_hi (np.clip,
+ * data_handling.py:333); pass clip_lo > clip_hi for no clamp. */
+int exabm4d_normalize_dev(exabm4d_ctx* ctx, const float* num, const float* den, float* out,
+                          size_t n, float clip_lo, float clip_hi);
+
+/* ---- BM4D whole pipeline ------------------------------------------------------------------- */
+/* stages: 1 = hard-threshold only, 2 = hard-threshold + Wiener.  in/out may alias. */
+int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
+                            int batch, float sigma, const exabm4d_params* p, int stages,
+                            float clip_lo, float clip_hi);
+/* uint16 in -> (float)in - offset -> BM4D -> + offset -> clamp [0,65535] -> rint -> uint16.
+ * (read_counts + bm4d + clip + the rint/uint16 cast of IntensityTransform.inverse.) */
+int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
+                            int nx, int batch, float sigma, float offset, const exabm4d_params* p,
+                            int stages);
+/* Host-pointer form of exabm4d_denoise_f32_dev (the bm4d(z, sigma) shim calls this). */
+int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
+                             int batch, float sigma, const exabm4d_params* p, int stages,
+                             float clip_lo, float clip_hi);
+
+/* ---- intensity transforms (a-D, a-E) ------------------------------------------------------- */
+int exabm4d_transform_forward_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const uint16_t* in, float* out, size_t n);
+int exabm4d_transform_forward_f32_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const float* in, float* out, size_t n);
+int exabm4d_transform_inverse_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const float* in, uint16_t* out, size_t n);
+int exabm4d_transform_inverse_f32_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                      const float* in, float* out, size_t n);
+
+/* ---- overlap-tile stitching around the BM4DNet stage (a-F, a-G) ----------------------------- */
+/* `starts` is a HOST array [nb][3] of patch corners (z,y,x); all other pointers are device
+ * pointers.  Gather nb cubic patches of edge `patch` from vol [nz][ny][nx] into
+ * out[nb][patch^3]; voxels beyond the volume are zero (add_padding, inference.py:178-199). */
+int exabm4d_tile_gather_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, int nx,
+                            const int32_t* starts, int nb, int patch, float* out);
+/* accum_pred[s:e] += pred[trim:-trim][: e-s]; accum_wgt[s:e] += 1 with s = start+trim,
+ * e = min(s + patch-2*trim, dim) per axis, patch after patch in array order so that the fp32
+ * sums are bit-identical to the reference's (inference.py:89-103). */
+int exabm4d_tile_accumulate_dev(exabm4d_ctx* ctx, const float* preds, const int32_t* starts,
+                                int nb, int patch, int trim, float* accum_pred, float* accum_wgt,
+                                int nz, int ny, int nx);
+/* out = transform.inverse(accum_pred / (accum_wgt + 1e-8f)) (inference.py:113-116). */
+int exabm4d_tile_finalize_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
+                                  const float* accum_pred, const float* accum_wgt, uint16_t* out,
+                                  size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXABM4D_H */

@@ -1,0 +1,177 @@
+"""ctypes front-end of the C oracle (oracle/exabm4d_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package never does.  PARITY UNPINNED with respect to the
+reference's third-party ``bm4d`` wheel (reference ``machine_learning/data_handling.py:332``);
+see the header of the C file and DESIGN.md section 3.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libexabm4d_oracle.so")
+_lib = None
+
+DEFAULTS = dict(lambda_ht=2.7, c_match_ht=3.0, c_match_wie=0.6, kaiser_beta=2.0)
+KEY_EMPTY = 0xFFFFFFFF
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "exabm4d_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        f32p = ctypes.POINTER(ctypes.c_float)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        u16p = ctypes.POINTER(ctypes.c_uint16)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        c_int, c_f, c_d, c_sz = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+        L.orc_grid_count.argtypes = [c_int]
+        L.orc_grid_count.restype = c_int
+        L.orc_grid_positions.argtypes = [c_int, i32p]
+        L.orc_tables.argtypes = [c_d, f32p, f32p]
+        L.orc_keymax.argtypes = [c_f, c_f]
+        L.orc_keymax.restype = ctypes.c_uint32
+        L.orc_blockmatch.argtypes = [f32p, c_int, c_int, c_int, c_f, c_f, u32p]
+        L.orc_group_transform.argtypes = [f32p, c_int, c_int]
+        L.orc_stage.argtypes = [f32p, f32p, u32p, c_int, c_int, c_int, c_f, c_f, c_d, f32p, f32p]
+        L.orc_normalize.argtypes = [f32p, f32p, f32p, c_sz, c_f, c_f]
+        L.orc_bm4d.argtypes = [f32p, f32p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_d, c_int,
+                               c_f, c_f]
+        L.orc_bm4d_u16.argtypes = [u16p, u16p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_d,
+                                   c_int]
+        L.orc_num_threads.restype = c_int
+        for name in ("orc_grid_positions", "orc_tables", "orc_blockmatch", "orc_group_transform",
+                     "orc_stage", "orc_normalize", "orc_bm4d", "orc_bm4d_u16"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def grid_positions(n):
+    c = lib().orc_grid_count(int(n))
+    pos = np.zeros(c, dtype=np.int32)
+    if c:
+        lib().orc_grid_positions(int(n), _p(pos, ctypes.c_int32))
+    return pos
+
+
+def tables(beta=DEFAULTS["kaiser_beta"]):
+    dct = np.zeros(64, dtype=np.float32)
+    win = np.zeros(512, dtype=np.float32)
+    lib().orc_tables(float(beta), _p(dct, ctypes.c_float), _p(win, ctypes.c_float))
+    return dct.reshape(8, 8), win.reshape(8, 8, 8)
+
+
+def keymax(sigma, c_match):
+    return int(lib().orc_keymax(float(sigma), float(c_match)))
+
+
+def blockmatch(vol, sigma, c_match=DEFAULTS["c_match_ht"]):
+    """-> keys [gz,gy,gx,16] uint32."""
+    vol = _f32(vol)
+    nz, ny, nx = vol.shape
+    g = [len(grid_positions(n)) for n in (nz, ny, nx)]
+    keys = np.empty((g[0], g[1], g[2], 16), dtype=np.uint32)
+    lib().orc_blockmatch(_p(vol, ctypes.c_float), nz, ny, nx, float(sigma), float(c_match),
+                         _p(keys, ctypes.c_uint32))
+    return keys
+
+
+def group_transform(g, inverse=False):
+    """In-place-semantics 4-D transform of a [K,8,8,8] group; returns a new array."""
+    g = _f32(g).copy()
+    lib().orc_group_transform(_p(g, ctypes.c_float), int(g.shape[0]), int(bool(inverse)))
+    return g
+
+
+def stage(noisy, keys, sigma, basic=None, lambda_ht=DEFAULTS["lambda_ht"],
+          beta=DEFAULTS["kaiser_beta"]):
+    """-> (num, den) of one collaborative-filtering stage (hard-threshold if basic is None)."""
+    noisy = _f32(noisy)
+    nz, ny, nx = noisy.shape
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    num = np.zeros_like(noisy)
+    den = np.zeros_like(noisy)
+    bp = None
+    if basic is not None:
+        basic = _f32(basic)
+        bp = _p(basic, ctypes.c_float)
+    lib().orc_stage(_p(noisy, ctypes.c_float), bp, _p(keys, ctypes.c_uint32), nz, ny, nx,
+                    float(sigma), float(lambda_ht), float(beta), _p(num, ctypes.c_float),
+                    _p(den, ctypes.c_float))
+    return num, den
+
+
+def normalize(num, den, clip=None):
+    num, den = _f32(num), _f32(den)
+    out = np.empty_like(num)
+    lo, hi = (1.0, 0.0) if clip is None else clip
+    lib().orc_normalize(_p(num, ctypes.c_float), _p(den, ctypes.c_float), _p(out, ctypes.c_float),
+                        num.size, float(lo), float(hi))
+    return out
+
+
+def bm4d(vol, sigma, stages=2, clip=None, **kw):
+    """Whole two-stage pipeline on one fp32 volume."""
+    p = {**DEFAULTS, **kw}
+    vol = _f32(vol)
+    nz, ny, nx = vol.shape
+    out = np.empty_like(vol)
+    lo, hi = (1.0, 0.0) if clip is None else clip
+    lib().orc_bm4d(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), nz, ny, nx, float(sigma),
+                   float(p["lambda_ht"]), float(p["c_match_ht"]), float(p["c_match_wie"]),
+                   float(p["kaiser_beta"]), int(stages), float(lo), float(hi))
+    return out
+
+
+def bm4d_u16(vol, sigma, offset, stages=2, **kw):
+    p = {**DEFAULTS, **kw}
+    vol = np.ascontiguousarray(vol, dtype=np.uint16)
+    nz, ny, nx = vol.shape
+    out = np.empty_like(vol)
+    lib().orc_bm4d_u16(_p(vol, ctypes.c_uint16), _p(out, ctypes.c_uint16), nz, ny, nx,
+                       float(sigma), float(offset), float(p["lambda_ht"]), float(p["c_match_ht"]),
+                       float(p["c_match_wie"]), float(p["kaiser_beta"]), int(stages))
+    return out
+
+
+def decode_keys(keys16):
+    """-> list of (dz,dy,dx), quantised distance S/512, for the valid entries."""
+    out = []
+    for k in np.asarray(keys16, dtype=np.uint32):
+        if int(k) == KEY_EMPTY:
+            break
+        code = int(k) & 0x7FF
+        if code == 0:
+            d = (0, 0, 0)
+        else:
+            l = code - 1
+            d = (l // 121 - 5, (l // 11) % 11 - 5, l % 11 - 5)
+        s = np.array([int(k) & 0xFFFFF800], dtype=np.uint32).view(np.float32)[0]
+        out.append((d, float(s) / 512.0))
+    return out

@@ -1,0 +1,153 @@
+"""GPU parity: BM4D kernels (through the C-ABI) vs the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): match tables bit-exact; estimates within fp32 tolerance
+(aggregation uses fp32 atomics, whose order is unspecified) and PSNR delta < 0.01 dB;
+uint16 outputs equal except where an fp32 ulp moves a value across a .5 boundary.
+"""
+import numpy as np
+import pytest
+
+from util import psnr, synth_volume
+
+pytestmark = pytest.mark.gpu
+
+SIGMA = 24.0
+
+
+def _keys_gpu(ctx, vol, sigma, c_match):
+    from aind_exaspim_image_compression import _native as nat
+    g = [len(nat.grid_positions(n)) for n in vol.shape]
+    d_vol = ctx.to_device(vol)
+    d_keys = ctx.alloc(g[0] * g[1] * g[2] * 16 * 4)
+    ctx.blockmatch(d_vol, vol.shape, sigma, c_match, d_keys)
+    ctx.sync()
+    return d_keys.download((g[0], g[1], g[2], 16), np.uint32)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (40, 44, 48), (8, 8, 8), (16, 12, 36),
+                                   (54, 54, 54), (30, 37, 41), (9, 10, 11)])
+def test_blockmatch_bit_exact(ctx, oracle, shape):
+    vol, _ = synth_volume(shape, seed=3)
+    want = oracle.blockmatch(vol, SIGMA, 3.0)
+    got = _keys_gpu(ctx, vol, SIGMA, 3.0)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+
+
+def test_blockmatch_generic_kernel_matches(ctx, oracle):
+    """The one-wave-per-block kernel alone must also reproduce the oracle bit for bit."""
+    vol, _ = synth_volume((36, 40, 44), seed=5)
+    want = oracle.blockmatch(vol, SIGMA, 3.0)
+    ctx.set_option("force_generic_bm", 1)
+    try:
+        got = _keys_gpu(ctx, vol, SIGMA, 3.0)
+    finally:
+        ctx.set_option("force_generic_bm", 0)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_blockmatch_constant_volume_self_first(ctx, oracle):
+    """All candidates tie at distance 0: the reference block itself must still be entry 0 and the
+    rest ordered by displacement code."""
+    vol = np.full((24, 24, 24), 5.0, dtype=np.float32)
+    got = _keys_gpu(ctx, vol, SIGMA, 3.0)
+    want = oracle.blockmatch(vol, SIGMA, 3.0)
+    np.testing.assert_array_equal(got, want)
+    assert np.all(got[..., 0] == 0)
+
+
+def test_blockmatch_wiener_threshold(ctx, oracle):
+    vol, _ = synth_volume((32, 32, 32), seed=7, sigma=4.0)
+    want = oracle.blockmatch(vol, SIGMA, 0.6)
+    got = _keys_gpu(ctx, vol, SIGMA, 0.6)
+    np.testing.assert_array_equal(got, want)
+
+
+def _stage_gpu(ctx, noisy, keys, sigma, basic=None):
+    d_noisy = ctx.to_device(noisy)
+    d_basic = ctx.to_device(basic) if basic is not None else None
+    d_keys = ctx.to_device(keys)
+    d_num = ctx.alloc(noisy.nbytes).zero()
+    d_den = ctx.alloc(noisy.nbytes).zero()
+    ctx.stage(d_noisy, d_basic, d_keys, noisy.shape, sigma, d_num, d_den)
+    ctx.sync()
+    return d_num.download(noisy.shape, np.float32), d_den.download(noisy.shape, np.float32)
+
+
+def _assert_close_estimates(got, want, sigma):
+    diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    tol = 1e-4 * sigma + 1e-5 * np.abs(want)
+    frac_bad = float(np.mean(diff > tol))
+    assert frac_bad < 1e-3, f"{frac_bad:.2e} of voxels outside fp32 tolerance, max {diff.max()}"
+    assert diff.max() < 0.05 * sigma
+
+
+@pytest.mark.parametrize("shape", [(40, 44, 48), (30, 37, 41)])
+def test_hard_threshold_stage(ctx, oracle, shape):
+    noisy, _ = synth_volume(shape, seed=11)
+    keys = oracle.blockmatch(noisy, SIGMA, 3.0)
+    num_w, den_w = oracle.stage(noisy, keys, SIGMA)
+    num_g, den_g = _stage_gpu(ctx, noisy, keys, SIGMA)
+    assert np.all(den_g > 0)
+    np.testing.assert_allclose(den_g, den_w, rtol=2e-5)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+
+
+def test_wiener_stage(ctx, oracle):
+    shape = (40, 44, 48)
+    noisy, _ = synth_volume(shape, seed=13)
+    basic = oracle.bm4d(noisy, SIGMA, stages=1)
+    keys = oracle.blockmatch(basic, SIGMA, 0.6)
+    num_w, den_w = oracle.stage(noisy, keys, SIGMA, basic=basic)
+    num_g, den_g = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic)
+    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+
+
+@pytest.mark.parametrize("stages", [1, 2])
+def test_pipeline_f32_psnr(ctx, oracle, stages):
+    shape = (64, 64, 64)
+    noisy, clean = synth_volume(shape, seed=17)
+    want = oracle.bm4d(noisy, SIGMA, stages=stages)
+    got = ctx.denoise_f32_host(noisy, SIGMA, stages=stages)
+    peak = float(clean.max() - clean.min())
+    p_w, p_g = psnr(want, clean, peak), psnr(got, clean, peak)
+    assert abs(p_w - p_g) < 0.01, (p_w, p_g)
+    assert p_g > psnr(noisy, clean, peak) + 8.0        # it actually denoises
+    assert psnr(got, want, peak) > 80.0
+    if stages == 1:
+        _assert_close_estimates(got, want, SIGMA)
+
+
+def test_pipeline_batch_of_patches(ctx, oracle):
+    """N independent 48^3 patches in one call == N single calls (precompute.py call pattern)."""
+    vols = np.stack([synth_volume((48, 48, 48), seed=s)[0] for s in (1, 2, 3)])
+    got = ctx.denoise_f32_host(vols, SIGMA, clip=(0.0, 65535.0))
+    for i in range(3):
+        want = np.clip(oracle.bm4d(vols[i], SIGMA), 0, 65535)
+        assert psnr(got[i], want, 1000.0) > 80.0
+
+
+def test_pipeline_u16(ctx, oracle):
+    shape = (48, 52, 56)
+    vol, _ = synth_volume(shape, seed=19, as_u16=True)
+    want = oracle.bm4d_u16(vol, SIGMA, 37.0)
+    d_in = ctx.to_device(vol)
+    d_out = ctx.alloc(vol.nbytes)
+    ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0)
+    ctx.sync()
+    got = d_out.download(shape, np.uint16)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1
+    assert np.mean(d > 0) < 2e-3
+
+
+def test_bad_arguments_raise(ctx):
+    from aind_exaspim_image_compression import _native as nat
+    with pytest.raises(ValueError):
+        ctx.denoise_f32_host(np.zeros((4, 8, 8), np.float32), SIGMA)       # axis < 8
+    with pytest.raises(ValueError):
+        ctx.denoise_f32_host(np.zeros((8, 8, 8), np.float32), -1.0)        # sigma <= 0
+    with pytest.raises(ValueError):
+        ctx.denoise_f32_host(np.zeros((8, 8, 8), np.float32), SIGMA,
+                             params=nat.default_params(block=4))           # unsupported profile
