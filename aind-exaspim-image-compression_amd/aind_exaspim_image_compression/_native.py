@@ -80,6 +80,7 @@ SIGNATURES = {
     "exabm4d_sync": (_I, [_CTX]),
     "exabm4d_default_params": (_I, [_PP]),
     "exabm4d_set_option": (_I, [_CTX, ctypes.c_char_p, _I]),
+    "exabm4d_profile_read": (_I, [_CTX, c_f32p, _I]),
     "exabm4d_malloc": (_I, [_CTX, _SZ, ctypes.POINTER(c_vp)]),
     "exabm4d_free": (_I, [_CTX, c_vp]),
     "exabm4d_memcpy_h2d": (_I, [_CTX, c_vp, c_vp, _SZ]),
@@ -242,6 +243,17 @@ class Context:
 
     def set_option(self, name, value):
         self._check(lib().exabm4d_set_option(self.handle, name.encode(), int(value)))
+
+    PHASES = ("counts_from_u16", "zero_acc_1", "blockmatch_ht", "stage_ht", "normalize_basic",
+              "zero_acc_2", "blockmatch_wie", "stage_wie", "normalize_out")
+
+    def profile_read(self):
+        """Per-phase milliseconds of the last denoise call (needs set_option('profile', 1))."""
+        ms = (ctypes.c_float * len(self.PHASES))()
+        n = lib().exabm4d_profile_read(self.handle, ms, len(self.PHASES))
+        if n < 0:
+            self._check(n)
+        return {name: float(ms[i]) for i, name in enumerate(self.PHASES[:n])}
 
     def set_stream(self, hip_stream):
         self._check(lib().exabm4d_set_stream(self.handle, hip_stream))

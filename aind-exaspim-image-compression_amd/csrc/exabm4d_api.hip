@@ -24,6 +24,9 @@ struct exabm4d_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
+    int profile = 0;           // exabm4d_set_option("profile")
+    hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
+    bool ev_used[EXABM4D_PHASE_COUNT] = {};
     std::string err;
 };
 
@@ -198,6 +201,8 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->win_dev) (void)hipFree(ctx->win_dev);
+    for (int i = 0; i < 2 * EXABM4D_PHASE_COUNT; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return EXABM4D_OK;
@@ -241,6 +246,12 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
     if (std::strcmp(name, "force_generic_bm") == 0) {
         ctx->force_generic_bm = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "profile") == 0) {
+        if (value && !ctx->ev[0])
+            for (int i = 0; i < 2 * EXABM4D_PHASE_COUNT; i++) HIP_TRY(ctx, hipEventCreate(&ctx->ev[i]));
+        ctx->profile = value ? 1 : 0;
         return EXABM4D_OK;
     }
     return fail(ctx, EXABM4D_ERR_INVALID, std::string("unknown option: ") + name);
@@ -396,6 +407,21 @@ int exabm4d_normalize_dev(exabm4d_ctx* ctx, const float* num, const float* den, 
     return EXABM4D_OK;
 }
 
+// Bracket one phase of a pipeline call with events when profiling is on.
+struct PhaseTimer {
+    exabm4d_ctx* ctx;
+    int phase;
+    PhaseTimer(exabm4d_ctx* c, int p) : ctx(c), phase(p) {
+        if (ctx->profile) (void)hipEventRecord(ctx->ev[2 * phase], ctx->stream);
+    }
+    ~PhaseTimer() {
+        if (ctx->profile) {
+            (void)hipEventRecord(ctx->ev[2 * phase + 1], ctx->stream);
+            ctx->ev_used[phase] = true;
+        }
+    }
+};
+
 // ---- whole pipeline -----------------------------------------------------------------------------------------
 // noisy: fp32 counts on device.  Exactly one of out_f32 / out_u16 is written.
 static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, uint16_t* out_u16,
@@ -413,26 +439,52 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
     hipStream_t s = ctx->stream;
+    if (ctx->profile)
+        for (int i = 1; i < EXABM4D_PHASE_COUNT; i++) ctx->ev_used[i] = false;
 
-    HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
-    HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
-    HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
-                                   ctx->force_generic_bm));
-    HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2,
-                              num, den, s));
-    if (stages >= 2) {
-        HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
+    {
+        PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_1);
         HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
         HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
-        HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys, s,
-                                       ctx->force_generic_bm));
-        HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2,
-                                  num, den, s));
     }
-    if (out_u16)
-        HIP_TRY(ctx, launch_normalize_u16(num, den, out_u16, n, u16_offset, s));
-    else
-        HIP_TRY(ctx, launch_normalize(num, den, out_f32, n, clip_lo, clip_hi, s));
+    {
+        PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);
+        HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
+                                       ctx->force_generic_bm));
+    }
+    {
+        PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
+        HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr,
+                                  sigma2, num, den, s));
+    }
+    if (stages >= 2) {
+        {
+            PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_BASIC);
+            HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
+        }
+        {
+            PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_2);
+            HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
+            HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+        }
+        {
+            PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
+            HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys,
+                                           s, ctx->force_generic_bm));
+        }
+        {
+            PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
+            HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
+                                      sigma2, num, den, s));
+        }
+    }
+    {
+        PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_OUT);
+        if (out_u16)
+            HIP_TRY(ctx, launch_normalize_u16(num, den, out_u16, n, u16_offset, s));
+        else
+            HIP_TRY(ctx, launch_normalize(num, den, out_f32, n, clip_lo, clip_hi, s));
+    }
     return EXABM4D_OK;
 }
 
@@ -473,7 +525,11 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
     if (rc) return rc;
     char* scratch = static_cast<char*>(ctx->scratch);
     float* noisy = reinterpret_cast<float*>(scratch + base);
-    HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream));
+    ctx->ev_used[EXABM4D_PHASE_COUNTS_FROM_U16] = false;
+    {
+        PhaseTimer t(ctx, EXABM4D_PHASE_COUNTS_FROM_U16);
+        HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream));
+    }
     return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
                         scratch);
 }
@@ -497,6 +553,18 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return EXABM4D_OK;
+}
+
+int exabm4d_profile_read(exabm4d_ctx* ctx, float* ms, int max_phases) {
+    if (!ctx || !ms) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (!ctx->ev[0]) return fail(ctx, EXABM4D_ERR_INVALID, "profiling was never enabled");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int n = max_phases < EXABM4D_PHASE_COUNT ? max_phases : EXABM4D_PHASE_COUNT;
+    for (int i = 0; i < n; i++) {
+        ms[i] = 0.0f;
+        if (ctx->ev_used[i]) HIP_TRY(ctx, hipEventElapsedTime(&ms[i], ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+    }
+    return n;
 }
 
 // ---- intensity transforms ---------------------------------------------------------------------------------

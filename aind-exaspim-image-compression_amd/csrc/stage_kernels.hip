@@ -1,11 +1,23 @@
 // stage_kernels.hip -- grouped 4-D collaborative filtering + overlap-add aggregation
-// (SURVEY.md section 8 rows a-B2 .. a-B5; DESIGN.md 3.5-3.8).  Checker: oracle orc_stage.
+// (SURVEY.md section 8 rows a-B2 .. a-B5; DESIGN.md 3.5-3.8, 5.2).  Checker: oracle orc_stage.
 //
-// One 256-lane workgroup per reference block (group).  The K <= 16 matched 8^3 blocks are
-// gathered into an LDS tile, transformed by a separable 8-point DCT-II along x, y, z (even/odd
-// folded, 4-term fmaf chains -- bit-identical to the oracle) and a Haar transform along the group
-// axis, shrunk (hard threshold, or empirical Wiener against the basic estimate's spectrum),
-// transformed back and scattered into the num/den accumulators with fp32 atomics.
+// Structure (MI355X-first; there is no reference kernel to follow):
+//   * A workgroup owns a 4x4 tile of reference-grid points in (y,x) and MARCHES along z.  The
+//     num/den accumulators of everything its groups can touch -- 18 z-planes x 30 x 30 voxels --
+//     live in an LDS ring (130 KB of the CU's 160 KB).  Blocks are added with LDS float atomics;
+//     a plane leaves the ring exactly once, through global float atomics on whole 120-byte row
+//     segments.  Global atomic bytes drop from 64 KB to ~1.8 KB per group (the memory-side
+//     atomic units sustain ~1.3 TB/s, MI355X_MICROARCH.md "Global float atomics").
+//   * One wave processes one group.  The group's spectrum lives in registers: 8 x <16 x float>
+//     per lane (coefficient plane j, block k).  Each block goes through gather -> DCT(y) ->
+//     LDS transpose -> DCT(x) -> LDS transpose -> DCT(z); the Haar transform along the group
+//     and the shrinkage then run entirely in registers.
+//   * Lane layouts of one 8^3 block (8 values per lane):
+//       L1: lane = (z,x), regs = y    gather / scatter (LDS adds conflict-free: bank = 8z + x)
+//       L2: lane = (z,y), regs = x
+//       L3: lane = (x,y), regs = z    spectrum layout
+// All DCT arithmetic is the even/odd-folded 4-term fmaf chain of DESIGN.md 3.5 and is
+// bit-identical to the oracle; only the order of the atomic sums differs.
 #include "exabm4d_kernels.h"
 
 namespace exabm4d {
@@ -14,10 +26,14 @@ struct DctTable {
     float d[64];  // [u][n], orthonormal DCT-II, rounded once from double (exabm4d_tables)
 };
 
-constexpr int ZS = 72;            // LDS stride of a z-plane (64 + 8 pad: conflict-free y pass)
-constexpr int PB = 8 * ZS;        // LDS stride of a block
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int TILE_R = 4;                 // grid points per tile edge in y and x
+constexpr int REG = 30;                   // ring region edge: 12 (3 steps) + 8 (block) + 2*5
+constexpr int PS = 904;                   // ring plane stride: 900 padded to 8 (mod 32)
+constexpr int NPL = 18;                   // ring planes: z0-5 .. z0+12
+constexpr int TBUF = 576;                 // per-wave transpose buffer (8 planes x 72 floats)
 constexpr float HAAR_C = 0.70710678118654752440f;
-constexpr int META_FLOATS = 64;  // block corners, K, nnz, partial sums at the end of the LDS region
 
 __device__ __forceinline__ float chain4(float c0, float v0, float c1, float v1, float c2, float v2,
                                         float c3, float v3) {
@@ -58,12 +74,13 @@ __device__ __forceinline__ void dct8_inv(const DctTable& T, float (&v)[8]) {
     for (int n = 0; n < 8; n++) v[n] = x[n];
 }
 
+// Orthonormal Haar along the group axis on the first K elements of a <16 x float>.
 template <int K>
-__device__ __forceinline__ void haar_fwd(float (&v)[MAXG]) {
-    float t[MAXG];
+__device__ __forceinline__ void haar_fwd(f16v& v) {
 #pragma unroll
     for (int len = K; len > 1; len >>= 1) {
         const int half = len >> 1;
+        float t[MAXG];
 #pragma unroll
         for (int i = 0; i < half; i++) {
             t[i] = (v[2 * i] + v[2 * i + 1]) * HAAR_C;
@@ -74,10 +91,10 @@ __device__ __forceinline__ void haar_fwd(float (&v)[MAXG]) {
     }
 }
 template <int K>
-__device__ __forceinline__ void haar_inv(float (&v)[MAXG]) {
-    float t[MAXG];
+__device__ __forceinline__ void haar_inv(f16v& v) {
 #pragma unroll
     for (int len = 1; len < K; len <<= 1) {
+        float t[MAXG];
 #pragma unroll
         for (int i = 0; i < len; i++) {
             t[2 * i] = (v[i] + v[len + i]) * HAAR_C;
@@ -88,208 +105,313 @@ __device__ __forceinline__ void haar_inv(float (&v)[MAXG]) {
     }
 }
 
-// 1-D DCT along LDS stride `stride` for `ncol` columns whose base offsets come from colbase(c).
-template <bool INV, typename F>
-__device__ __forceinline__ void lds_dct_pass(float* g, const DctTable& T, int ncol, int stride,
-                                             F colbase) {
-    for (int c = threadIdx.x; c < ncol; c += 256) {
-        float* p = g + colbase(c);
-        float v[8];
-#pragma unroll
-        for (int n = 0; n < 8; n++) v[n] = p[n * stride];
-        if (INV)
-            dct8_inv(T, v);
-        else
-            dct8_fwd(T, v);
-#pragma unroll
-        for (int n = 0; n < 8; n++) p[n * stride] = v[n];
-    }
+// The transpose buffer is private to one wave and LDS executes a wave's instructions in order,
+// so a compiler-level fence is all that is needed between its writes and reads.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Gather the K blocks of `vol` (x-DCT applied on the fly) into the LDS tile.
-__device__ __forceinline__ void gather_fwd_x(float* g, const float* __restrict__ vol,
-                                             const int* bpos, int K, size_t sy, size_t sz,
-                                             const DctTable& T) {
-    for (int r = threadIdx.x; r < K * 64; r += 256) {
-        const int k = r >> 6, z = (r >> 3) & 7, y = r & 7;
-        const float* p = vol + (size_t)(bpos[3 * k] + z) * sz + (size_t)(bpos[3 * k + 1] + y) * sy +
-                         bpos[3 * k + 2];
-        float v[8];
-#pragma unroll
-        for (int n = 0; n < 8; n++) v[n] = p[n];
-        dct8_fwd(T, v);
-        float4* q = reinterpret_cast<float4*>(g + k * PB + z * ZS + y * 8);
-        q[0] = make_float4(v[0], v[1], v[2], v[3]);
-        q[1] = make_float4(v[4], v[5], v[6], v[7]);
-    }
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-template <bool WIENER, int K>
-__device__ __forceinline__ void shrink_pass(float* g, float* gb, float thr, float sigma2,
-                                            int& nnz, float& sw) {
-    for (int p = threadIdx.x; p < BVOX; p += 256) {
-        const int o = (p >> 6) * ZS + (p & 63);
-        float v[MAXG];
+// Gather one block (corner `src`) and return its 3-D DCT in layout L3.
+__device__ __forceinline__ void block_fwd(const float* __restrict__ src, size_t sy, size_t sz,
+                                          const DctTable& T, float* tb, int hi, int lo,
+                                          float (&v)[8]) {
+    const float* p = src + (size_t)hi * sz + lo;               // L1: hi = z, lo = x
 #pragma unroll
-        for (int k = 0; k < K; k++) v[k] = g[k * PB + o];
-        haar_fwd<K>(v);
-        if (!WIENER) {
+    for (int y = 0; y < 8; y++) v[y] = p[(size_t)y * sy];
+    dct8_fwd(T, v);                                             // along y
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const bool keep = fabsf(v[k]) >= thr;
-                nnz += keep ? 1 : 0;
-                v[k] = keep ? v[k] : 0.0f;
-            }
-        } else {
-            float b[MAXG];
+    for (int y = 0; y < 8; y++) tb[hi * 72 + y * 8 + lo] = v[y];   // buffer [z][y][x]
+    wave_lds_sync();
+    load8(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
+    wave_lds_sync();
+    dct8_fwd(T, v);                                             // along x
 #pragma unroll
-            for (int k = 0; k < K; k++) b[k] = gb[k * PB + o];
-            haar_fwd<K>(b);
+    for (int x = 0; x < 8; x++) tb[x * 64 + lo * 8 + hi] = v[x];   // buffer [x][y][z]
+    wave_lds_sync();
+    load8(tb + hi * 64 + lo * 8, v);                            // L3: hi = x, lo = y, regs z
+    wave_lds_sync();
+    dct8_fwd(T, v);                                             // along z
+}
+
+// Inverse of block_fwd: L3 spectrum in, spatial block in layout L1 out.
+__device__ __forceinline__ void block_inv(const DctTable& T, float* tb, int hi, int lo,
+                                          float (&v)[8]) {
+    dct8_inv(T, v);                                             // along z (L3: hi = x, lo = y)
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const float e = b[k] * b[k];
-                const float W = e / (e + sigma2);
-                v[k] = W * v[k];
-                sw += W * W;
-            }
+    for (int z = 0; z < 8; z++) tb[z * 72 + lo * 8 + hi] = v[z];   // buffer [z][y][x]
+    wave_lds_sync();
+    load8(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
+    wave_lds_sync();
+    dct8_inv(T, v);                                             // along x
+#pragma unroll
+    for (int x = 0; x < 8; x++) tb[hi * 72 + x * 8 + lo] = v[x];   // buffer [z][x][y]
+    wave_lds_sync();
+    load8(tb + hi * 72 + lo * 8, v);                            // L1: hi = z, lo = x, regs y
+    wave_lds_sync();
+    dct8_inv(T, v);                                             // along y
+}
+
+template <int K>
+__device__ __forceinline__ void shrink_ht(f16v (&spec)[8], float thr, int& nnz) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        f16v s = spec[j];
+        haar_fwd<K>(s);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool keep = fabsf(s[k]) >= thr;
+            nnz += keep ? 1 : 0;
+            s[k] = keep ? s[k] : 0.0f;
         }
-        haar_inv<K>(v);
+        haar_inv<K>(s);
+        spec[j] = s;
+    }
+}
+template <int K>
+__device__ __forceinline__ void shrink_wiener(f16v (&spec)[8], f16v (&bspec)[8], float sigma2,
+                                              float& sw) {
 #pragma unroll
-        for (int k = 0; k < K; k++) g[k * PB + o] = v[k];
+    for (int j = 0; j < 8; j++) {
+        f16v s = spec[j], b = bspec[j];
+        haar_fwd<K>(s);
+        haar_fwd<K>(b);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float e = b[k] * b[k];
+            const float W = e / (e + sigma2);
+            s[k] = W * s[k];
+            sw += W * W;
+        }
+        haar_inv<K>(s);
+        spec[j] = s;
     }
 }
 
-template <bool WIENER>
-__global__ __launch_bounds__(256) void stage_kernel(const float* __restrict__ noisy_all,
-                                                    const float* __restrict__ basic_all,
-                                                    const uint32_t* __restrict__ keys_all,
-                                                    VolGeom g, DctTable T,
-                                                    const float* __restrict__ win, float thr,
-                                                    float sigma2, float* __restrict__ num_all,
-                                                    float* __restrict__ den_all) {
-    // One dynamic LDS region (no static __shared__ in front of it: keeps the base 16-B aligned).
-    extern __shared__ __align__(16) float lds[];
-    float* gn = lds;                             // noisy group   [16][PB]
-    float* gb = lds + (WIENER ? MAXG * PB : 0);  // basic group   [16][PB] (Wiener only)
-    float* meta = lds + (WIENER ? 2 : 1) * MAXG * PB;
-    int* bpos = reinterpret_cast<int*>(meta);            // [3*16] block corners (z,y,x)
-    int& s_K = *reinterpret_cast<int*>(meta + 48);
-    int& s_nnz = *reinterpret_cast<int*>(meta + 49);
-    float* s_sw = meta + 52;                             // [4] per-wave partial sums
+struct TileGeom {
+    int y0, x0;       // voxel coordinates of ring region element (0,0): first ref position - 5
+    int nry, nrx;     // grid points of this tile in y and x (1..4)
+};
 
-    const size_t voff = (size_t)blockIdx.y * (size_t)g.nvox;
+// One wave, one group.
+template <bool WIENER>
+__device__ __forceinline__ void process_group(const float* __restrict__ noisy,
+                                              const float* __restrict__ basic,
+                                              const uint32_t* __restrict__ kk, int rz, int ry,
+                                              int rx, const TileGeom& tg, size_t sy, size_t sz,
+                                              const DctTable& T, const float (&win)[8], float thr,
+                                              float sigma2, float* rnum, float* rden, float* tb,
+                                              int lane) {
+    const int hi = lane >> 3, lo = lane & 7;
+    const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
+    const int count = __popcll(__ballot(mykey != KEY_EMPTY));
+    int K = 1;
+    while (K * 2 <= count) K *= 2;
+
+    f16v spec[8];
+    f16v bspec[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        spec[j] = (f16v)(0.0f);
+        bspec[j] = (f16v)(0.0f);
+    }
+
+    for (int k = 0; k < K; k++) {
+        const uint32_t key = __builtin_amdgcn_readlane(mykey, k);
+        int dz, dy, dx;
+        code_to_disp(key & KEY_CMASK, dz, dy, dx);
+        const size_t corner = (size_t)(rz + dz) * sz + (size_t)(ry + dy) * sy + (size_t)(rx + dx);
+        float v[8];
+        block_fwd(noisy + corner, sy, sz, T, tb, hi, lo, v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) spec[j][k] = v[j];
+        if (WIENER) {
+            block_fwd(basic + corner, sy, sz, T, tb, hi, lo, v);
+#pragma unroll
+            for (int j = 0; j < 8; j++) bspec[j][k] = v[j];
+        }
+    }
+
+    float w;
+    if (!WIENER) {
+        int nnz = 0;
+        switch (K) {
+            case 16: shrink_ht<16>(spec, thr, nnz); break;
+            case 8: shrink_ht<8>(spec, thr, nnz); break;
+            case 4: shrink_ht<4>(spec, thr, nnz); break;
+            case 2: shrink_ht<2>(spec, thr, nnz); break;
+            default: shrink_ht<1>(spec, thr, nnz); break;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
+        w = 1.0f / (sigma2 * (float)(nnz > 1 ? nnz : 1));
+    } else {
+        float sw = 0.0f;
+        switch (K) {
+            case 16: shrink_wiener<16>(spec, bspec, sigma2, sw); break;
+            case 8: shrink_wiener<8>(spec, bspec, sigma2, sw); break;
+            case 4: shrink_wiener<4>(spec, bspec, sigma2, sw); break;
+            case 2: shrink_wiener<2>(spec, bspec, sigma2, sw); break;
+            default: shrink_wiener<1>(spec, bspec, sigma2, sw); break;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
+        w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
+    }
+
+    float ww[8];
+#pragma unroll
+    for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+
+    for (int k = 0; k < K; k++) {
+        const uint32_t key = __builtin_amdgcn_readlane(mykey, k);
+        int dz, dy, dx;
+        code_to_disp(key & KEY_CMASK, dz, dy, dx);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = spec[j][k];
+        block_inv(T, tb, hi, lo, v);                            // L1: hi = z, lo = x, regs y
+        int slot = (rz + dz + 5) % NPL + hi;
+        slot -= slot >= NPL ? NPL : 0;
+        const int off = slot * PS + (ry + dy - tg.y0) * REG + (rx + dx - tg.x0) + lo;
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            atomicAdd(rnum + off + y * REG, ww[y] * v[y]);
+            atomicAdd(rden + off + y * REG, ww[y]);
+        }
+    }
+}
+
+// Move ring planes [zlo, zhi) to global memory (float atomics: neighbouring tiles overlap) and
+// zero them.  Whole workgroup.
+__device__ __forceinline__ void flush_planes(float* rnum, float* rden, float* __restrict__ num,
+                                             float* __restrict__ den, int zlo, int zhi,
+                                             const TileGeom& tg, const VolGeom& g, int nthreads) {
+    const int nplanes = zhi - zlo;
+    for (int i = threadIdx.x; i < nplanes * REG * REG; i += nthreads) {
+        const int pl = i / (REG * REG), rem = i - pl * (REG * REG);
+        const int z = zlo + pl;
+        const int slot = (z + 5) % NPL;
+        const int o = slot * PS + rem;
+        const float d = rden[o];
+        if (d != 0.0f) {
+            const int ryy = rem / REG, rxx = rem - ryy * REG;
+            const int y = tg.y0 + ryy, x = tg.x0 + rxx;
+            // d != 0 implies a block covered this voxel, so it lies inside the volume
+            const size_t go = ((size_t)z * g.ny + y) * g.nx + x;
+            atomicAdd(num + go, rnum[o]);
+            atomicAdd(den + go, d);
+            rnum[o] = 0.0f;
+            rden[o] = 0.0f;
+        }
+    }
+}
+
+template <bool WIENER, int NW>
+__global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
+    const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
+    const uint32_t* __restrict__ keys_all, VolGeom g, DctTable T, const float* __restrict__ win_g,
+    float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ den_all, int tiles_x,
+    int layers_per_chunk) {
+    extern __shared__ __align__(16) float lds[];
+    float* rnum = lds;
+    float* rden = lds + NPL * PS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* tb = lds + 2 * NPL * PS + wave * TBUF;
+
+    const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
     const float* __restrict__ noisy = noisy_all + voff;
     const float* __restrict__ basic = WIENER ? basic_all + voff : nullptr;
     float* __restrict__ num = num_all + voff;
     float* __restrict__ den = den_all + voff;
-    const long long r = blockIdx.x;
-    const uint32_t* __restrict__ kk = keys_all + ((size_t)blockIdx.y * (size_t)g.nref + (size_t)r) * MAXG;
+    const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
-    const int tid = threadIdx.x;
 
-    if (tid < MAXG) {
-        const int ix = (int)(r % g.gx), iy = (int)((r / g.gx) % g.gy),
-                  iz = (int)(r / ((long long)g.gx * g.gy));
-        const uint32_t key = kk[tid];
-        int dz, dy, dx;
-        code_to_disp(key & KEY_CMASK, dz, dy, dx);
-        bpos[3 * tid + 0] = grid_pos(iz, g.az, g.nz) + dz;
-        bpos[3 * tid + 1] = grid_pos(iy, g.ay, g.ny) + dy;
-        bpos[3 * tid + 2] = grid_pos(ix, g.ax, g.nx) + dx;
-        const unsigned long long m = __ballot(key != KEY_EMPTY) & 0xFFFFull;
-        if (tid == 0) {
-            const int count = __popcll(m);
-            int K = 1;
-            while (K * 2 <= count) K *= 2;
-            s_K = K;
-            s_nnz = 0;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int iy0 = TILE_R * ty, ix0 = TILE_R * tx;
+    TileGeom tg;
+    tg.nry = min(TILE_R, g.gy - iy0);
+    tg.nrx = min(TILE_R, g.gx - ix0);
+    tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
+    tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
+    const int nrefs = tg.nry * tg.nrx;
+
+    const int izb = blockIdx.y * layers_per_chunk;
+    const int ize = min(g.gz, izb + layers_per_chunk);
+
+    for (int i = threadIdx.x; i < 2 * NPL * PS; i += NW * 64) lds[i] = 0.0f;
+
+    // aggregation window of this lane in layout L1 (lane = (z,x), regs y)
+    float win[8];
+    {
+        const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+        for (int y = 0; y < 8; y++) win[y] = win_g[(hi * 8 + y) * 8 + lo];
+    }
+    __syncthreads();
+
+    int base = grid_pos(izb, g.az, g.nz) - RAD;   // lowest plane held by the ring
+    for (int iz = izb; iz < ize; iz++) {
+        const int z0 = grid_pos(iz, g.az, g.nz);
+        if (z0 - RAD > base) {
+            flush_planes(rnum, rden, num, den, base, z0 - RAD, tg, g, NW * 64);
+            base = z0 - RAD;
+            __syncthreads();
         }
-    }
-    __syncthreads();
-    const int K = s_K;
-
-    // forward: x (on the fly), y, z
-    gather_fwd_x(gn, noisy, bpos, K, sy, sz, T);
-    if (WIENER) gather_fwd_x(gb, basic, bpos, K, sy, sz, T);
-    __syncthreads();
-    auto col_y = [](int c) { return (c >> 6) * PB + ((c >> 3) & 7) * ZS + (c & 7); };
-    auto col_z = [](int c) { return (c >> 6) * PB + (c & 63); };
-    lds_dct_pass<false>(gn, T, K * 64, 8, col_y);
-    if (WIENER) lds_dct_pass<false>(gb, T, K * 64, 8, col_y);
-    __syncthreads();
-    lds_dct_pass<false>(gn, T, K * 64, ZS, col_z);
-    if (WIENER) lds_dct_pass<false>(gb, T, K * 64, ZS, col_z);
-    __syncthreads();
-
-    // Haar along the group + shrinkage + inverse Haar
-    int nnz = 0;
-    float sw = 0.0f;
-    switch (K) {
-        case 16: shrink_pass<WIENER, 16>(gn, gb, thr, sigma2, nnz, sw); break;
-        case 8: shrink_pass<WIENER, 8>(gn, gb, thr, sigma2, nnz, sw); break;
-        case 4: shrink_pass<WIENER, 4>(gn, gb, thr, sigma2, nnz, sw); break;
-        case 2: shrink_pass<WIENER, 2>(gn, gb, thr, sigma2, nnz, sw); break;
-        default: shrink_pass<WIENER, 1>(gn, gb, thr, sigma2, nnz, sw); break;
-    }
-    if (!WIENER) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
-        if ((tid & 63) == 0) atomicAdd(&s_nnz, nnz);
-    } else {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
-        if ((tid & 63) == 0) s_sw[tid >> 6] = sw;
-    }
-    __syncthreads();
-    float w;
-    if (!WIENER) {
-        const int n = s_nnz;
-        w = 1.0f / (sigma2 * (float)(n > 1 ? n : 1));
-    } else {
-        const float s = (s_sw[0] + s_sw[1]) + (s_sw[2] + s_sw[3]);
-        w = 1.0f / (sigma2 * (s > 1.0f ? s : 1.0f));
-    }
-
-    // inverse: z, y, then x fused with the scatter
-    lds_dct_pass<true>(gn, T, K * 64, ZS, col_z);
-    __syncthreads();
-    lds_dct_pass<true>(gn, T, K * 64, 8, col_y);
-    __syncthreads();
-    for (int rr = tid; rr < K * 64; rr += 256) {
-        const int k = rr >> 6, z = (rr >> 3) & 7, y = rr & 7;
-        const float4* q = reinterpret_cast<const float4*>(gn + k * PB + z * ZS + y * 8);
-        const float4 a = q[0], b = q[1];
-        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        dct8_inv(T, v);
-        const size_t o = (size_t)(bpos[3 * k] + z) * sz + (size_t)(bpos[3 * k + 1] + y) * sy +
-                        (size_t)bpos[3 * k + 2];
-        const float* wr = win + (z * 8 + y) * 8;
-#pragma unroll
-        for (int x = 0; x < 8; x++) {
-            const float ww = w * wr[x];
-            atomicAdd(num + o + x, ww * v[x]);
-            atomicAdd(den + o + x, ww);
+        for (int r = wave; r < nrefs; r += NW) {
+            const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
+            const int iy = iy0 + jy, ix = ix0 + jx;
+            const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
+            const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
+            process_group<WIENER>(noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2,
+                                  rnum, rden, tb, lane);
         }
+        __syncthreads();
     }
+    flush_planes(rnum, rden, num, den, base, base + NPL, tg, g, NW * 64);
 }
+
+constexpr int NW_HT = 8;
+constexpr int NW_WIE = 4;
 
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
-    dim3 grid((unsigned)g.nref, (unsigned)batch);
+    const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
+    // Split z into chunks when there are too few tiles to fill 256 CUs (small volumes / patches).
+    const long long tiles = (long long)tiles_y * tiles_x * batch;
+    int chunks = (int)((1024 + tiles - 1) / tiles);
+    if (chunks < 1) chunks = 1;
+    if (chunks > g.gz) chunks = g.gz;
+    const int lpc = (g.gz + chunks - 1) / chunks;
+    chunks = (g.gz + lpc - 1) / lpc;
+    dim3 grid((unsigned)(tiles_y * tiles_x), (unsigned)chunks, (unsigned)batch);
     if (basic) {
-        const size_t lds = sizeof(float) * (2 * MAXG * PB + META_FLOATS);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * TBUF);
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&stage_tile_kernel<true, NW_WIE>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(stage_kernel<true>, grid, dim3(256), lds, stream, noisy, basic, keys, g,
-                           T, win_dev, thr, sigma2, num, den);
+        hipLaunchKernelGGL((stage_tile_kernel<true, NW_WIE>), grid, dim3(NW_WIE * 64), lds, stream,
+                           noisy, basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, lpc);
     } else {
-        const size_t lds = sizeof(float) * (MAXG * PB + META_FLOATS);
-        hipLaunchKernelGGL(stage_kernel<false>, grid, dim3(256), lds, stream, noisy, basic, keys, g,
-                           T, win_dev, thr, sigma2, num, den);
+        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_HT * TBUF);
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&stage_tile_kernel<false, NW_HT>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((stage_tile_kernel<false, NW_HT>), grid, dim3(NW_HT * 64), lds, stream,
+                           noisy, basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, lpc);
     }
     return hipGetLastError();
 }

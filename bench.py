@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the BM4D denoise hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Step  = one pass of the hot path over one synthetic uint16 volume that is already resident in
+        HBM: uint16 counts -> fp32 - offset -> block matching -> hard-threshold stage -> basic
+        estimate -> block matching -> Wiener stage -> normalise -> + offset -> clip -> rint ->
+        uint16, through the C-ABI entry exabm4d_denoise_u16_dev (include/exabm4d.h).
+Metric = BASELINE.json's "denoised+encoded voxels/s on 1024^3 uint16" (the reference's only
+        quantiser is the rint/uint16 cast; its entropy coder is third-party Blosc, out of scope).
+N > 1 = one process per GPU (torch.distributed / RCCL for the barrier and the max over ranks);
+        every rank denoises its own volume, no data-path collective ("weak" scaling).
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel, timed live with HIP
+events recorded on the stream the kernels run on (exabm4d "profile" option) inside the timed
+region.  `cpu_baseline` times the CPU oracle (a port: the reference's BM4D is a closed wheel that
+cannot travel) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "aind-exaspim-image-compression_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+SIGMA = 24.0      # reference scripts/precompute.py:284
+OFFSET = 37.0     # reference scripts/evaluate_bm4dnet.py:207
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# ALGORITHMIC bytes per input voxel of each kernel.  Match records are
+# 16 x 4-byte keys per reference block = 64 B / 64 voxels = 1 B/voxel.
+ALGO_BYTES_PER_VOXEL = {
+    "counts_from_u16": 2 + 4,
+    "blockmatch_ht": 4 + 1,
+    "stage_ht": 1 + 4 + 8,
+    "normalize_basic": 8 + 4,
+    "blockmatch_wie": 4 + 1,
+    "stage_wie": 1 + 4 + 4 + 8,
+    "normalize_out": 8 + 2,
+}
+
+
+def synth_u16(shape, seed):
+    """Pedestal 37 + blurred bright random-walk 'neurites' (a 128^3 brick, mirror-tiled) +
+    N(0, 24) noise, rint, clip, uint16.  Deterministic in `seed`."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    b = 128
+    brick = np.zeros((b, b, b), dtype=np.float32)
+    for _ in range(48):
+        p = rng.uniform(0, b, 3)
+        amp = float(np.exp(rng.uniform(np.log(100.0), np.log(8000.0))))
+        for _ in range(int(rng.integers(200, 800))):
+            p = np.clip(p + rng.normal(0, 0.7, 3), 0, b - 1)
+            brick[int(p[0]), int(p[1]), int(p[2])] += amp
+    brick = gaussian_filter(brick, 1.5) * 12.0
+    nz, ny, nx = shape
+
+    def tile_axis(n):
+        idx = np.arange(n) % (2 * b)
+        return np.where(idx < b, idx, 2 * b - 1 - idx)
+
+    iz, iy, ix = tile_axis(nz), tile_axis(ny), tile_axis(nx)
+    out = np.empty(shape, dtype=np.uint16)
+    slab = 32
+    for z0 in range(0, nz, slab):
+        z1 = min(nz, z0 + slab)
+        clean = brick[iz[z0:z1]][:, iy][:, :, ix] + np.float32(OFFSET)
+        noise = rng.standard_normal(clean.shape, dtype=np.float32) * np.float32(SIGMA)
+        out[z0:z1] = np.rint(np.clip(clean + noise, 0, 65535)).astype(np.uint16)
+    return out
+
+
+def cpu_baseline(sample_edge, seed):
+    """CPU oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
+    from oracle import bm4d_oracle
+    bm4d_oracle.build()
+    vol = synth_u16((sample_edge,) * 3, seed)
+    t0 = time.perf_counter()
+    bm4d_oracle.bm4d_u16(vol, SIGMA, OFFSET, stages=2)
+    dt = time.perf_counter() - t0
+    return {
+        "value": vol.size / dt,
+        "unit": "voxels/s",
+        "cores": bm4d_oracle.num_threads(),
+        "kind": "port",
+        "sample": f"{sample_edge}^3 uint16 synthetic sub-volume, two-stage BM4D, "
+                  f"C oracle with OpenMP, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1024, help="cubic volume edge per GPU")
+    ap.add_argument("--stages", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=128,
+                    help="edge of the CPU-baseline sample (0 disables the baseline)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from aind_exaspim_image_compression import _native
+
+    ctx = _native.context(local_rank)
+    shape = (args.size,) * 3
+    nvox = int(np.prod(shape))
+    vol = synth_u16(shape, seed=1000 + rank)
+    d_in = ctx.to_device(vol)
+    d_out = ctx.alloc(vol.nbytes)
+    params = _native.default_params()
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        ctx.denoise_u16(d_in, d_out, shape, SIGMA, OFFSET, params=params, stages=args.stages)
+
+    ctx.set_option("profile", 1)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    phase_ms = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in ctx.profile_read().items():      # waits for this step's events only
+            phase_ms[k] = phase_ms.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # size-independent sanity property at full size: output is a denoised version of the input
+    out = d_out.download(shape, np.uint16)
+    sl = (slice(0, min(64, shape[0])),)
+    resid = out[sl].astype(np.float32) - vol[sl].astype(np.float32)
+    resid_std = float(resid.std())
+
+    if rank == 0:
+        phase_avg = {k: v / max(args.steps, 1) for k, v in phase_ms.items() if v > 0}
+        kern = {k: v for k, v in phase_avg.items() if k in ALGO_BYTES_PER_VOXEL}
+        dom = max(kern, key=kern.get)
+        achieved = ALGO_BYTES_PER_VOXEL[dom] * nvox / (kern[dom] * 1e-3) / 1e9
+        result = {
+            "metric": "denoised+encoded voxels/s on 1024^3 uint16",
+            "value": world * nvox * args.steps / elapsed,
+            "unit": "voxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.size}^3 uint16 volume per GPU, two-stage BM4D "
+                            "(hard-threshold + Wiener), 8^3 blocks step 4, 11^3 search, "
+                            "16-block groups, sigma 24, offset 37; u16 in HBM -> u16 in HBM"
+                            if args.stages == 2 else
+                            f"{args.size}^3 uint16 volume per GPU, hard-threshold stage only",
+                "volume": list(shape),
+                "stages": args.stages,
+                "sharding": "one independent volume per rank, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_voxel": ALGO_BYTES_PER_VOXEL[dom],
+                "avg_ms": kern[dom],
+            },
+            "phase_ms": phase_avg,
+            "residual_std": resid_std,
+        }
+        if args.cpu_sample > 0:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000)
+        print(json.dumps(result), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,23 @@ int exabm4d_default_params(exabm4d_params* p);
  * one-wave-per-block matching kernel (normally used only for grid points that are not a
  * multiple of 4); the parity tests use it to check the two kernels against each other. */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
+/* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
+ * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and
+ * returns its per-phase durations in milliseconds, in EXABM4D_PHASE_* order (0 for a phase the
+ * call did not run); returns the number of phases written (<= max_phases) or a negative status. */
+enum {
+    EXABM4D_PHASE_COUNTS_FROM_U16 = 0,
+    EXABM4D_PHASE_ZERO_ACC_1 = 1,
+    EXABM4D_PHASE_BLOCKMATCH_HT = 2,
+    EXABM4D_PHASE_STAGE_HT = 3,
+    EXABM4D_PHASE_NORMALIZE_BASIC = 4,
+    EXABM4D_PHASE_ZERO_ACC_2 = 5,
+    EXABM4D_PHASE_BLOCKMATCH_WIE = 6,
+    EXABM4D_PHASE_STAGE_WIE = 7,
+    EXABM4D_PHASE_NORMALIZE_OUT = 8,
+    EXABM4D_PHASE_COUNT = 9
+};
+int exabm4d_profile_read(exabm4d_ctx* ctx, float* ms, int max_phases);
 
 /* ---- device memory helpers (for ctypes hosts without torch) ------------------------------ */
 int exabm4d_malloc(exabm4d_ctx* ctx, size_t bytes, void** dptr);
