@@ -4,7 +4,7 @@
 // Structure (MI355X-first; there is no reference kernel to follow):
 //   * A workgroup owns a 4x4 tile of reference-grid points in (y,x) and MARCHES along z.  The
 //     num/den accumulators of everything its groups can touch -- 18 z-planes x 30 x 30 voxels --
-//     live in an LDS ring (130 KB of the CU's 160 KB).  Blocks are added with LDS float atomics;
+//     live in an LDS ring (130 KB of the CU's 160 KB).  Blocks are added by plain LDS read-modify-writes under a workgroup lock;
 //     a plane leaves the ring exactly once, through global float atomics on whole 120-byte row
 //     segments.  Global atomic bytes drop from 64 KB to ~1.8 KB per group (the memory-side
 //     atomic units sustain ~1.3 TB/s, MI355X_MICROARCH.md "Global float atomics").
@@ -27,6 +27,23 @@ struct DctTable {
 };
 
 typedef float f16v __attribute__((ext_vector_type(16)));
+
+#ifdef EXABM4D_STAMPS
+// Diagnostic build only: per-phase cycle sums (s_memtime) accumulated over all waves.
+__device__ unsigned long long g_stamps[16];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp()
+#define STAMP_ADD(i, a, b) st[i] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(i, a, b)
+#endif
 
 constexpr int TILE_R = 4;                 // grid points per tile edge in y and x
 constexpr int REG = 30;                   // ring region edge: 12 (3 steps) + 8 (block) + 2*5
@@ -105,13 +122,10 @@ __device__ __forceinline__ void haar_inv(f16v& v) {
     }
 }
 
-// The transpose buffer is private to one wave and LDS executes a wave's instructions in order,
-// so a compiler-level fence is all that is needed between its writes and reads.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// The transpose buffers are private to one wave and LDS executes a wave's instructions in issue
+// order, so between a buffer's writes and its (cross-lane) reads only the COMPILER must be kept
+// from reordering; no s_waitcnt or barrier is needed.
+__device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
 
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
     const float4 a = *reinterpret_cast<const float4*>(p);
@@ -120,44 +134,71 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
     v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-// Gather one block (corner `src`) and return its 3-D DCT in layout L3.
-__device__ __forceinline__ void block_fwd(const float* __restrict__ src, size_t sy, size_t sz,
-                                          const DctTable& T, float* tb, int hi, int lo,
-                                          float (&v)[8]) {
-    const float* p = src + (size_t)hi * sz + lo;               // L1: hi = z, lo = x
+// Issue the gather of one block (corner `src`) in layout L1 (hi = z, lo = x, regs y).
+__device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy, size_t sz, int hi,
+                                        int lo, float (&v)[8]) {
+    const float* p = src + (size_t)hi * sz + lo;
 #pragma unroll
     for (int y = 0; y < 8; y++) v[y] = p[(size_t)y * sy];
-    dct8_fwd(T, v);                                             // along y
-#pragma unroll
-    for (int y = 0; y < 8; y++) tb[hi * 72 + y * 8 + lo] = v[y];   // buffer [z][y][x]
-    wave_lds_sync();
-    load8(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
-    wave_lds_sync();
-    dct8_fwd(T, v);                                             // along x
-#pragma unroll
-    for (int x = 0; x < 8; x++) tb[x * 64 + lo * 8 + hi] = v[x];   // buffer [x][y][z]
-    wave_lds_sync();
-    load8(tb + hi * 64 + lo * 8, v);                            // L3: hi = x, lo = y, regs z
-    wave_lds_sync();
-    dct8_fwd(T, v);                                             // along z
 }
 
-// Inverse of block_fwd: L3 spectrum in, spatial block in layout L1 out.
-__device__ __forceinline__ void block_inv(const DctTable& T, float* tb, int hi, int lo,
-                                          float (&v)[8]) {
-    dct8_inv(T, v);                                             // along z (L3: hi = x, lo = y)
+// 3-D DCT of TWO blocks at once (independent streams a, b with their own transpose buffers, so
+// that the LDS round trips of one overlap the arithmetic of the other).  In: layout L1, out: L3.
+__device__ __forceinline__ void pair_fwd(const DctTable& T, float* ta, float* tb, int hi, int lo,
+                                         float (&a)[8], float (&b)[8]) {
+    dct8_fwd(T, a);                                             // along y
+    dct8_fwd(T, b);
 #pragma unroll
-    for (int z = 0; z < 8; z++) tb[z * 72 + lo * 8 + hi] = v[z];   // buffer [z][y][x]
-    wave_lds_sync();
-    load8(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
-    wave_lds_sync();
-    dct8_inv(T, v);                                             // along x
+    for (int y = 0; y < 8; y++) {                               // buffer [z][y][x]
+        ta[hi * 72 + y * 8 + lo] = a[y];
+        tb[hi * 72 + y * 8 + lo] = b[y];
+    }
+    cbar();
+    load8(ta + hi * 72 + lo * 8, a);                            // L2: hi = z, lo = y, regs x
+    load8(tb + hi * 72 + lo * 8, b);
+    cbar();
+    dct8_fwd(T, a);                                             // along x
+    dct8_fwd(T, b);
 #pragma unroll
-    for (int x = 0; x < 8; x++) tb[hi * 72 + x * 8 + lo] = v[x];   // buffer [z][x][y]
-    wave_lds_sync();
-    load8(tb + hi * 72 + lo * 8, v);                            // L1: hi = z, lo = x, regs y
-    wave_lds_sync();
-    dct8_inv(T, v);                                             // along y
+    for (int x = 0; x < 8; x++) {                               // buffer [x][y][z]
+        ta[x * 64 + lo * 8 + hi] = a[x];
+        tb[x * 64 + lo * 8 + hi] = b[x];
+    }
+    cbar();
+    load8(ta + hi * 64 + lo * 8, a);                            // L3: hi = x, lo = y, regs z
+    load8(tb + hi * 64 + lo * 8, b);
+    cbar();
+    dct8_fwd(T, a);                                             // along z
+    dct8_fwd(T, b);
+}
+
+// Inverse of pair_fwd: L3 spectra in, spatial blocks in layout L1 out.
+__device__ __forceinline__ void pair_inv(const DctTable& T, float* ta, float* tb, int hi, int lo,
+                                         float (&a)[8], float (&b)[8]) {
+    dct8_inv(T, a);                                             // along z (L3: hi = x, lo = y)
+    dct8_inv(T, b);
+#pragma unroll
+    for (int z = 0; z < 8; z++) {                               // buffer [z][y][x]
+        ta[z * 72 + lo * 8 + hi] = a[z];
+        tb[z * 72 + lo * 8 + hi] = b[z];
+    }
+    cbar();
+    load8(ta + hi * 72 + lo * 8, a);                            // L2: hi = z, lo = y, regs x
+    load8(tb + hi * 72 + lo * 8, b);
+    cbar();
+    dct8_inv(T, a);                                             // along x
+    dct8_inv(T, b);
+#pragma unroll
+    for (int x = 0; x < 8; x++) {                               // buffer [z][x][y]
+        ta[hi * 72 + x * 8 + lo] = a[x];
+        tb[hi * 72 + x * 8 + lo] = b[x];
+    }
+    cbar();
+    load8(ta + hi * 72 + lo * 8, a);                            // L1: hi = z, lo = x, regs y
+    load8(tb + hi * 72 + lo * 8, b);
+    cbar();
+    dct8_inv(T, a);                                             // along y
+    dct8_inv(T, b);
 }
 
 template <int K>
@@ -196,6 +237,18 @@ __device__ __forceinline__ void shrink_wiener(f16v (&spec)[8], f16v (&bspec)[8],
     }
 }
 
+// Workgroup-wide spin lock in LDS (one lane of the wave takes it for the whole wave).
+__device__ __forceinline__ void ring_lock(int* lock, int lane) {
+    if (lane == 0) {
+        while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void ring_unlock(int* lock, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicExch(lock, 0);
+}
+
 struct TileGeom {
     int y0, x0;       // voxel coordinates of ring region element (0,0): first ref position - 5
     int nry, nrx;     // grid points of this tile in y and x (1..4)
@@ -208,9 +261,14 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
                                               const uint32_t* __restrict__ kk, int rz, int ry,
                                               int rx, const TileGeom& tg, size_t sy, size_t sz,
                                               const DctTable& T, const float (&win)[8], float thr,
-                                              float sigma2, float* rnum, float* rden, float* tb,
-                                              int lane) {
+                                              float sigma2, float* rnum, float* rden, float* ta,
+                                              float* tb, int* lock, int lane
+#ifdef EXABM4D_STAMPS
+                                              , unsigned long long (&st)[16]
+#endif
+                                              ) {
     const int hi = lane >> 3, lo = lane & 7;
+    STAMP(t0);
     const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
     const int count = __popcll(__ballot(mykey != KEY_EMPTY));
     int K = 1;
@@ -224,22 +282,59 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
         bspec[j] = (f16v)(0.0f);
     }
 
-    for (int k = 0; k < K; k++) {
+    // Forward transforms, two streams per iteration: (noisy k, basic k) for Wiener, blocks
+    // (k, k+1) for the hard-threshold stage.  The next iteration's gather is issued before the
+    // current pair is transformed so that its latency hides behind the arithmetic.
+    auto corner_of = [&](int k) -> size_t {
         const uint32_t key = __builtin_amdgcn_readlane(mykey, k);
         int dz, dy, dx;
         code_to_disp(key & KEY_CMASK, dz, dy, dx);
-        const size_t corner = (size_t)(rz + dz) * sz + (size_t)(ry + dy) * sy + (size_t)(rx + dx);
-        float v[8];
-        block_fwd(noisy + corner, sy, sz, T, tb, hi, lo, v);
-#pragma unroll
-        for (int j = 0; j < 8; j++) spec[j][k] = v[j];
+        return (size_t)(rz + dz) * sz + (size_t)(ry + dy) * sy + (size_t)(rx + dx);
+    };
+    const int kstep = WIENER ? 1 : 2;
+    float a[8], b[8], na[8] = {}, nb[8] = {};
+    {
+        const size_t c0 = corner_of(0);
+        gather8(noisy + c0, sy, sz, hi, lo, a);
+        if (WIENER)
+            gather8(basic + c0, sy, sz, hi, lo, b);
+        else
+            gather8(noisy + corner_of(K > 1 ? 1 : 0), sy, sz, hi, lo, b);
+    }
+    for (int k = 0; k < K; k += kstep) {
+        const int kn = k + kstep;
+        if (kn < K) {
+            const size_t c0 = corner_of(kn);
+            gather8(noisy + c0, sy, sz, hi, lo, na);
+            if (WIENER)
+                gather8(basic + c0, sy, sz, hi, lo, nb);
+            else
+                gather8(noisy + corner_of(kn + 1), sy, sz, hi, lo, nb);
+        }
+        pair_fwd(T, ta, tb, hi, lo, a, b);
         if (WIENER) {
-            block_fwd(basic + corner, sy, sz, T, tb, hi, lo, v);
 #pragma unroll
-            for (int j = 0; j < 8; j++) bspec[j][k] = v[j];
+            for (int j = 0; j < 8; j++) {
+                spec[j][k] = a[j];
+                bspec[j][k] = b[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) spec[j][k] = a[j];
+            if (K > 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) spec[j][k + 1] = b[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            a[j] = na[j];
+            b[j] = nb[j];
         }
     }
 
+    STAMP(t1);
+    STAMP_ADD(0, t0, t1);
     float w;
     if (!WIENER) {
         int nnz = 0;
@@ -270,24 +365,59 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
     float ww[8];
 #pragma unroll
     for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+    STAMP(t2);
+    STAMP_ADD(1, t1, t2);
 
+    // Inverse 3-D DCT of every block (two per iteration), results kept in the spectrum
+    // registers (now layout L1: hi = z, lo = x, plane index = y).
+    for (int k = 0; k < K; k += 2) {
+        const int k2 = (k + 1 < K) ? k + 1 : k;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            a[j] = spec[j][k];
+            b[j] = spec[j][k2];
+        }
+        pair_inv(T, ta, tb, hi, lo, a, b);
+#pragma unroll
+        for (int j = 0; j < 8; j++) spec[j][k] = a[j];
+        if (k2 != k) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) spec[j][k2] = b[j];
+        }
+    }
+
+    // Aggregate into the LDS ring.  LDS float atomics (ds_add_f32) run at about one lane per
+    // two cycles on gfx950 (measured: 76 LDS-array cycles per LDS instruction with them), so
+    // the adds are plain read-modify-writes under a workgroup lock instead.  LDS executes
+    // instructions in issue order, so within the lock holder overlapping blocks of one group
+    // are added correctly one after the other.
+    STAMP(t3);
+    STAMP_ADD(2, t2, t3);
+    ring_lock(lock, lane);
+    STAMP(t4);
+    STAMP_ADD(3, t3, t4);
     for (int k = 0; k < K; k++) {
         const uint32_t key = __builtin_amdgcn_readlane(mykey, k);
         int dz, dy, dx;
         code_to_disp(key & KEY_CMASK, dz, dy, dx);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = spec[j][k];
-        block_inv(T, tb, hi, lo, v);                            // L1: hi = z, lo = x, regs y
         int slot = (rz + dz + 5) % NPL + hi;
         slot -= slot >= NPL ? NPL : 0;
         const int off = slot * PS + (ry + dy - tg.y0) * REG + (rx + dx - tg.x0) + lo;
+        float an[8], ad[8];
 #pragma unroll
         for (int y = 0; y < 8; y++) {
-            atomicAdd(rnum + off + y * REG, ww[y] * v[y]);
-            atomicAdd(rden + off + y * REG, ww[y]);
+            an[y] = rnum[off + y * REG];
+            ad[y] = rden[off + y * REG];
+        }
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            rnum[off + y * REG] = an[y] + ww[y] * spec[y][k];
+            rden[off + y * REG] = ad[y] + ww[y];
         }
     }
+    ring_unlock(lock, lane);
+    STAMP(t5);
+    STAMP_ADD(4, t4, t5);
 }
 
 // Move ring planes [zlo, zhi) to global memory (float atomics: neighbouring tiles overlap) and
@@ -325,7 +455,9 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     float* rnum = lds;
     float* rden = lds + NPL * PS;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* tb = lds + 2 * NPL * PS + wave * TBUF;
+    float* ta = lds + 2 * NPL * PS + wave * 2 * TBUF;
+    float* tb = ta + TBUF;
+    int* lock = reinterpret_cast<int*>(lds + 2 * NPL * PS + NW * 2 * TBUF);
 
     const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
     const float* __restrict__ noisy = noisy_all + voff;
@@ -348,6 +480,7 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     const int ize = min(g.gz, izb + layers_per_chunk);
 
     for (int i = threadIdx.x; i < 2 * NPL * PS; i += NW * 64) lds[i] = 0.0f;
+    if (threadIdx.x == 0) *lock = 0;
 
     // aggregation window of this lane in layout L1 (lane = (z,x), regs y)
     float win[8];
@@ -359,27 +492,46 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     __syncthreads();
 
     int base = grid_pos(izb, g.az, g.nz) - RAD;   // lowest plane held by the ring
+#ifdef EXABM4D_STAMPS
+    unsigned long long st[16] = {};
+    const unsigned long long tk0 = stamp();
+#endif
     for (int iz = izb; iz < ize; iz++) {
         const int z0 = grid_pos(iz, g.az, g.nz);
+        STAMP(tf0);
         if (z0 - RAD > base) {
             flush_planes(rnum, rden, num, den, base, z0 - RAD, tg, g, NW * 64);
             base = z0 - RAD;
             __syncthreads();
         }
+        STAMP(tf1);
+        STAMP_ADD(5, tf0, tf1);
         for (int r = wave; r < nrefs; r += NW) {
             const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
             const int iy = iy0 + jy, ix = ix0 + jx;
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
             const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
             process_group<WIENER>(noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2,
-                                  rnum, rden, tb, lane);
+                                  rnum, rden, ta, tb, lock, lane
+#ifdef EXABM4D_STAMPS
+                                  , st
+#endif
+                                  );
         }
+        STAMP(tb0);
         __syncthreads();
+        STAMP(tb1);
+        STAMP_ADD(6, tb0, tb1);
     }
     flush_planes(rnum, rden, num, den, base, base + NPL, tg, g, NW * 64);
+#ifdef EXABM4D_STAMPS
+    st[7] = stamp() - tk0;
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i + (WIENER ? 8 : 0)], st[i]);
+#endif
 }
 
-constexpr int NW_HT = 8;
+constexpr int NW_HT = 4;
 constexpr int NW_WIE = 4;
 
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
@@ -397,7 +549,7 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
     chunks = (g.gz + lpc - 1) / lpc;
     dim3 grid((unsigned)(tiles_y * tiles_x), (unsigned)chunks, (unsigned)batch);
     if (basic) {
-        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * TBUF);
+        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * 2 * TBUF + 4);
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void*>(&stage_tile_kernel<true, NW_WIE>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -405,7 +557,7 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         hipLaunchKernelGGL((stage_tile_kernel<true, NW_WIE>), grid, dim3(NW_WIE * 64), lds, stream,
                            noisy, basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, lpc);
     } else {
-        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_HT * TBUF);
+        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_HT * 2 * TBUF + 4);
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void*>(&stage_tile_kernel<false, NW_HT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -415,5 +567,14 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
     }
     return hipGetLastError();
 }
+
+#ifdef EXABM4D_STAMPS
+extern "C" void exabm4d_debug_stamps(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(z));
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+}
+#endif
 
 }  // namespace exabm4d
