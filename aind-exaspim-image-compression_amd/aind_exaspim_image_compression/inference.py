@@ -1,0 +1,184 @@
+"""GPU-resident tiled BM4DNet inference (drop-in for the reference ``inference.py``).
+
+Same functions, signatures, defaults and return types as the reference
+(``predict`` inference.py:28, ``predict_patch`` :119, ``load_model`` :255,
+``build_volume_transform`` :302, helpers :178-252, :340-380).  What differs is where the work
+happens: the reference transforms the volume with numpy, gathers patches with a thread pool,
+copies every batch to and from the device and adds 8000 patches into host accumulators in a
+Python loop (hot loops 1-2 of SURVEY.md section 3-A).  Here the volume is uploaded once; the
+intensity transform, patch gather + zero padding, trim + overlap-add and the final
+normalise -> inverse transform -> rint -> uint16 are HIP kernels of ``libexabm4d.so`` working on
+buffers that stay in HBM, and only the uint16 result comes back.  The U-Net itself is PyTorch-ROCm.
+
+Reference quirk kept on purpose (inference.py:91-103): the first ``trim``
+voxels along every axis receive zero weight and come out as ``transform.inverse(0)``.
+"""
+import itertools
+import os
+
+import numpy as np
+import torch
+
+from aind_exaspim_image_compression import _native
+from aind_exaspim_image_compression.machine_learning.transforms import (
+    build_transform,
+    estimate_offset,
+    with_offset,
+)
+from aind_exaspim_image_compression.machine_learning.unet3d import N2V2UNet, UNet
+
+
+def _model_device(model):
+    try:
+        dev = next(model.parameters()).device
+    except (StopIteration, AttributeError):
+        dev = None
+    if dev is None or dev.type != "cuda":
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    return dev
+
+
+def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, trim=5,
+            verbose=True):
+    """Denoise a 3-D image by overlapping-patch inference; returns uint16 counts.
+
+    Parameters follow the reference (inference.py:28-67): ``img`` is a 3-D array (leading
+    singleton axes are accepted), ``model`` a torch module (or any callable on a
+    ``(B,1,P,P,P)`` float32 CUDA tensor), ``transform`` the IntensityTransform the model was
+    trained with."""
+    img = np.asarray(img)
+    while img.ndim > 3:
+        if img.shape[0] != 1:
+            raise ValueError("predict expects a single 3-D volume")
+        img = img[0]
+    if img.ndim != 3:
+        raise ValueError("predict expects a 3-D volume")
+    shape = tuple(int(s) for s in img.shape)
+    n = int(np.prod(shape))
+    dev = _model_device(model)
+    ctx = _native.context(dev.index or 0)
+
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev)
+        ctx.set_stream(stream.cuda_stream)       # kernels and the model share one stream
+        src_u16 = img.dtype == np.uint16
+        host = np.ascontiguousarray(img if src_u16 else img.astype(np.float32))
+        d_raw = torch.from_numpy(host.view(np.int16) if src_u16 else host).to(dev)
+        vol = torch.empty(shape, dtype=torch.float32, device=dev)
+        transform.forward_device(ctx, d_raw, vol, n, src_u16)          # inference.py:69
+        del d_raw
+
+        accum_pred = torch.zeros(shape, dtype=torch.float32, device=dev)   # inference.py:81-82
+        accum_wgt = torch.zeros(shape, dtype=torch.float32, device=dev)
+        starts = list(generate_patch_starts(_ShapeOnly((1, 1) + shape), patch_size, overlap))
+        pbar = None
+        if verbose:
+            from tqdm import tqdm
+            pbar = tqdm(total=len(starts), desc="Denoise")
+        batch = torch.empty((batch_size, 1, patch_size, patch_size, patch_size),
+                            dtype=torch.float32, device=dev)
+        for b0 in range(0, len(starts), batch_size):
+            chunk = np.asarray(starts[b0:b0 + batch_size], dtype=np.int32)
+            nb = len(chunk)
+            ctx.tile_gather(vol, shape, chunk, patch_size, batch)      # inference.py:153-168
+            with torch.no_grad():
+                out = model(batch[:nb])                                # inference.py:171-173
+            out = out.to(torch.float32).contiguous()
+            ctx.tile_accumulate(out, chunk, patch_size, trim, accum_pred, accum_wgt, shape)
+            if pbar is not None:
+                pbar.update(nb)
+        del vol
+        result = torch.empty(shape, dtype=torch.int16, device=dev)
+        ctx.tile_finalize(transform.native_struct(), accum_pred, accum_wgt, result, n)
+        stream.synchronize()
+        out = result.cpu().numpy().view(np.uint16)
+        ctx.set_stream(None)
+    if pbar is not None:
+        pbar.close()
+    return out
+
+
+def predict_patch(patch, model, transform):
+    """Denoise one patch (reference inference.py:119-150); uint16, same shape as the input."""
+    patch = np.asarray(patch)
+    shape = patch.shape[-3:]
+    x = transform.forward(patch.reshape(shape))
+    dev = _model_device(model)
+    with torch.no_grad():
+        pred = model(to_tensor(x, device=dev))
+    return transform.inverse(pred[0, 0].float().cpu().numpy())
+
+
+# --- helpers (reference inference.py:178-252) -------------------------------------------------
+class _ShapeOnly:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+def add_padding(patch, patch_size):
+    """Zero-pad a 3-D patch at the high end of each axis up to ``patch_size`` (host helper kept
+    for API parity; ``predict`` pads inside the gather kernel)."""
+    patch = np.asarray(patch)
+    pad = [(0, patch_size - s) for s in patch.shape]
+    return np.pad(patch, pad, mode="constant", constant_values=0)
+
+
+def generate_patch_starts(img, patch_size, overlap):
+    """Patch corner coordinates: ``range(0, dim - patch + stride, stride)`` per spatial axis of
+    a ``(1, 1, D, H, W)`` image, z outermost."""
+    stride = patch_size - overlap
+    axes = [range(0, img.shape[a] - patch_size + stride, stride) for a in (2, 3, 4)]
+    return itertools.product(*axes)
+
+
+def count_patches(img, patch_size, overlap):
+    stride = patch_size - overlap
+    n = 1
+    for a in (2, 3, 4):
+        n *= len(range(0, img.shape[a] - patch_size + stride, stride))
+    return n
+
+
+def load_model(path, device="cuda"):
+    """Load a checkpoint -> ``(model.eval(), transform)`` (reference inference.py:255-299).
+
+    Accepts the current format ``{"model", "model_config", "transform"}`` and a bare legacy
+    ``state_dict`` (transform then defaults to asinh).  Unlike the reference, ``N2V2UNet``
+    checkpoints work (the reference forgets to import the class: inference.py:290-291)."""
+    ckpt = torch.load(path, map_location=device)
+    if isinstance(ckpt, dict) and "model" in ckpt:
+        state_dict = ckpt["model"]
+        transform_cfg = ckpt.get("transform") or {"kind": "asinh"}
+        model_cfg = dict(ckpt.get("model_config") or {})
+    else:
+        state_dict, transform_cfg, model_cfg = ckpt, {"kind": "asinh"}, {}
+    cls = N2V2UNet if model_cfg.pop("model", "UNet") == "N2V2UNet" else UNet
+    model = cls(**model_cfg)
+    model.load_state_dict(state_dict)
+    model.to(device)
+    model.eval()
+    return model, build_transform(transform_cfg)
+
+
+def build_volume_transform(base_transform, img=None, percentile=0.1, offset=None):
+    """Inference transform carrying a per-volume background offset (reference
+    inference.py:302-337): a supplied ``offset`` is used as is, otherwise it is estimated from
+    ``img``; ``ValueError`` if neither is given."""
+    if offset is None:
+        if img is None:
+            raise ValueError("img is required when offset is not supplied")
+        offset = estimate_offset(img, percentile=percentile, ignore_zeros=True)
+    return with_offset(base_transform, offset)
+
+
+def to_tensor(arr, device="cuda"):
+    """numpy -> float tensor of shape (1, 1, D, H, W) on ``device`` (inference.py:340-359)."""
+    arr = np.asarray(arr)
+    while arr.ndim < 5:
+        arr = arr[np.newaxis, ...]
+    return torch.tensor(arr).to(device, dtype=torch.float)
+
+
+def batch_to_tensor(arr, device="cuda"):
+    """(B, D, H, W) numpy -> (B, 1, D, H, W) float tensor (inference.py:362-380)."""
+    return to_tensor(np.asarray(arr)[:, np.newaxis, ...], device=device)

@@ -1,0 +1,87 @@
+"""N > 1 path on CPU: two gloo ranks run the slab sharding + halo exchange of
+aind_exaspim_image_compression.distributed with the ORACLE as the per-slab compute, and the
+stitched result must equal the whole-volume oracle result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import synth_volume
+
+from aind_exaspim_image_compression.distributed import SlabPlan, plan_slabs
+
+SIGMA = 24.0
+SHAPE = (112, 24, 28)
+
+
+def test_plan_slabs():
+    plans = [plan_slabs(1024, 8, r) for r in range(8)]
+    assert plans[0].z0 == 0 and plans[-1].z1 == 1024
+    for a, b in zip(plans, plans[1:]):
+        assert a.z1 == b.z0 and a.z1 % 4 == 0
+    assert plans[3].p0 == plans[3].z0 - 24 and plans[3].p1 == plans[3].z1 + 24
+    assert plans[0].p0 == 0 and plans[0].lo == 0 and plans[7].hi == 0
+    assert plans[3].core == slice(24, 24 + 128)
+    with pytest.raises(ValueError):
+        plan_slabs(64, 8, 0)                 # slabs thinner than the halo
+    with pytest.raises(ValueError):
+        plan_slabs(1024, 2, 0, halo=10)      # halo not a multiple of the grid step
+    one = plan_slabs(100, 1, 0)
+    assert (one.z0, one.z1, one.p0, one.p1) == (0, 100, 0, 100)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, tmp):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "aind-exaspim-image-compression_amd"),
+              os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
+    from aind_exaspim_image_compression.distributed import denoise_slab, plan_slabs
+    from oracle import bm4d_oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    vol, _ = synth_volume(SHAPE, seed=21)
+    plan = plan_slabs(SHAPE[0], world, rank)
+    noisy = torch.from_numpy(np.ascontiguousarray(vol[plan.p0:plan.p1]))
+
+    def stage1(x):
+        return torch.from_numpy(O.bm4d(x.numpy(), SIGMA, stages=1))
+
+    def stage2(x, basic):
+        keys = O.blockmatch(basic.numpy(), SIGMA, O.DEFAULTS["c_match_wie"])
+        num, den = O.stage(x.numpy(), keys, SIGMA, basic=basic.numpy())
+        return torch.from_numpy(O.normalize(num, den))
+
+    out = denoise_slab(noisy, plan, SIGMA, stage1, stage2)
+    np.save(os.path.join(tmp, f"slab{rank}.npy"), out.numpy())
+    np.save(os.path.join(tmp, f"plan{rank}.npy"), np.array([plan.z0, plan.z1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_slabs_equal_whole_volume(oracle, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    vol, _ = synth_volume(SHAPE, seed=21)
+    want = oracle.bm4d(vol, SIGMA)
+    got = np.empty_like(want)
+    for r in range(world):
+        z0, z1 = np.load(tmp_path / f"plan{r}.npy")
+        got[z0:z1] = np.load(tmp_path / f"slab{r}.npy")
+    # exact halo (24): identical up to the fp32 summation order of the aggregation
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)

@@ -1,0 +1,100 @@
+"""Self-consistency of the BM4D oracle (the reference holds no test for its third-party bm4d
+wheel -- parity unpinned -- so these are the properties SURVEY.md section 8c asks for).  CPU."""
+import numpy as np
+import pytest
+
+from util import psnr, synth_volume
+
+SIGMA = 24.0
+
+
+def test_grid_positions(oracle):
+    assert oracle.grid_positions(64).tolist() == list(range(0, 57, 4))
+    assert oracle.grid_positions(54).tolist() == list(range(0, 45, 4)) + [46]
+    assert oracle.grid_positions(8).tolist() == [0]
+    assert oracle.grid_positions(9).tolist() == [0, 1]
+    assert oracle.grid_positions(7).tolist() == []
+    for n, c in ((64, 15), (256, 63), (1024, 255), (272, 67)):
+        assert len(oracle.grid_positions(n)) == c
+
+
+def test_tables(oracle):
+    dct, win = oracle.tables(2.0)
+    np.testing.assert_allclose(dct @ dct.T, np.eye(8), atol=1e-6)       # orthonormal DCT-II
+    k = np.kaiser(8, 2.0)
+    np.testing.assert_allclose(win, k[:, None, None] * k[None, :, None] * k[None, None, :],
+                               rtol=1e-6)
+    _, ones = oracle.tables(0.0)
+    assert np.all(ones == 1.0)
+
+
+@pytest.mark.parametrize("K", [1, 2, 4, 8, 16])
+def test_group_transform_parseval_and_inverse(oracle, K):
+    g = np.random.default_rng(K).normal(size=(K, 8, 8, 8)).astype(np.float32)
+    G = oracle.group_transform(g)
+    assert abs(np.sum(G.astype(np.float64) ** 2) / np.sum(g.astype(np.float64) ** 2) - 1) < 1e-5
+    np.testing.assert_allclose(oracle.group_transform(G, inverse=True), g, atol=5e-6)
+    if K > 1:
+        const = np.ones((K, 8, 8, 8), np.float32)
+        C = oracle.group_transform(const)
+        assert abs(C[0, 0, 0, 0] - np.sqrt(K * 512.0)) < 1e-2       # all energy in DC
+        assert np.abs(C).sum() - abs(C[0, 0, 0, 0]) < 1e-2
+
+
+def test_match_table_invariants(oracle):
+    vol, _ = synth_volume((32, 36, 40), seed=2)
+    keys = oracle.blockmatch(vol, SIGMA, 3.0)
+    assert np.all(keys[..., 0] == 0)                                 # the block itself is first
+    valid = keys != 0xFFFFFFFF
+    body = keys.astype(np.int64)
+    assert np.all((np.diff(body, axis=-1) > 0) | ~valid[..., 1:])    # strictly ascending
+    assert np.all(keys[valid] < oracle.keymax(SIGMA, 3.0))
+    # candidates stay inside the volume
+    pz, py, px = (oracle.grid_positions(n) for n in vol.shape)
+    for (iz, iy, ix) in [(0, 0, 0), (len(pz) - 1, len(py) - 1, len(px) - 1), (3, 4, 5)]:
+        for (d, _) in oracle.decode_keys(keys[iz, iy, ix]):
+            c = np.array([pz[iz], py[iy], px[ix]]) + np.array(d)
+            assert np.all(c >= 0) and np.all(c + 8 <= np.array(vol.shape))
+
+
+def test_constant_volume_is_a_fixed_point(oracle):
+    vol = np.full((24, 24, 24), 123.0, dtype=np.float32)
+    np.testing.assert_allclose(oracle.bm4d(vol, SIGMA), vol, rtol=1e-5)
+
+
+def test_lambda_zero_is_identity(oracle):
+    vol, _ = synth_volume((24, 24, 28), seed=4)
+    np.testing.assert_allclose(oracle.bm4d(vol, SIGMA, stages=1, lambda_ht=0.0), vol,
+                               atol=2e-3)
+
+
+def test_small_sigma_returns_input(oracle):
+    vol, _ = synth_volume((24, 24, 24), seed=5)
+    out = oracle.bm4d(vol, 1e-3)
+    assert np.abs(out - vol).max() < 1e-2
+
+
+def test_psnr_gain_and_stage_order(oracle):
+    noisy, clean = synth_volume((48, 48, 48), seed=6)
+    peak = float(clean.max() - clean.min())
+    p0 = psnr(noisy, clean, peak)
+    p1 = psnr(oracle.bm4d(noisy, SIGMA, stages=1), clean, peak)
+    p2 = psnr(oracle.bm4d(noisy, SIGMA, stages=2), clean, peak)
+    assert p1 > p0 + 8.0
+    assert p2 > p1
+
+
+def test_u16_pipeline_equals_float_pipeline(oracle):
+    vol, _ = synth_volume((24, 28, 32), seed=8, as_u16=True)
+    f = oracle.bm4d(vol.astype(np.float32) - np.float32(37.0), SIGMA)
+    want = np.rint(np.clip(f + np.float32(37.0), 0, 65535)).astype(np.uint16)
+    np.testing.assert_array_equal(oracle.bm4d_u16(vol, SIGMA, 37.0), want)
+
+
+def test_crop_invariance(oracle):
+    """A voxel's result depends on input within 48 voxels (two stages x 24), and the reference
+    grid of a crop whose origin is a multiple of 4 coincides with the volume's."""
+    vol, _ = synth_volume((40, 40, 120), seed=9)
+    full = oracle.bm4d(vol, SIGMA)
+    crop = oracle.bm4d(vol[:, :, 4:116], SIGMA)
+    np.testing.assert_allclose(crop[:, :, 48:-48], full[:, :, 52:-52], rtol=1e-4, atol=1e-3)
