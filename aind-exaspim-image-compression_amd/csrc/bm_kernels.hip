@@ -17,8 +17,90 @@ namespace exabm4d {
 // Tile kernel: 512 lanes = 8x8x8 cells; tiles overlap by one cell so a tile yields 7x7x7
 // grid-aligned reference blocks.
 // ------------------------------------------------------------------------------------------------
+// 16-byte load from a 4-byte aligned address (gfx950 global loads need only dword alignment;
+// hipcc emits global_load_dwordx4 for this type).
+struct __attribute__((packed, aligned(4))) float4u {
+    float x, y, z, w;
+};
+
 constexpr int TC = 8;        // cells per tile edge
 constexpr int TR = TC - 1;   // reference blocks per tile edge
+
+template <bool WIDE>
+__device__ __forceinline__ void bm_tile_loop(const float* __restrict__ vol, const VolGeom& g,
+                                             uint32_t keymax, const float (&A)[64],
+                                             const int (&xo)[14], int qz, int qy, int qx, int rz,
+                                             int ry, int rx, bool ref_ok, int tid, size_t sy,
+                                             size_t sz, float (*cs)[TC * TC * TC],
+                                             uint32_t (&list)[MAXG]) {
+    for (int dzi = 0; dzi < SWIN; dzi++) {
+        const int dz = dzi - RAD;
+        const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
+        for (int dyi = 0; dyi < SWIN; dyi++) {
+            const int dy = dyi - RAD;
+            const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
+
+            float acc[SWIN];
+#pragma unroll
+            for (int d = 0; d < SWIN; d++) acc[d] = 0.0f;
+
+#pragma unroll
+            for (int z = 0; z < 4; z++) {
+                const int wz = min(max(qz + z + dz, 0), g.nz - 1);
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    const int wy = min(max(qy + y + dy, 0), g.ny - 1);
+                    const float* __restrict__ rowp = vol + (size_t)wz * sz + (size_t)wy * sy;
+                    float w[16];
+                    if (WIDE) {
+                        const float4u* q = reinterpret_cast<const float4u*>(rowp + (qx - RAD));
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float4u t4 = q[j];
+                            w[4 * j] = t4.x;
+                            w[4 * j + 1] = t4.y;
+                            w[4 * j + 2] = t4.z;
+                            w[4 * j + 3] = t4.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 14; j++) w[j] = rowp[xo[j]];
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const float a = A[(z * 4 + y) * 4 + x];
+#pragma unroll
+                        for (int d = 0; d < SWIN; d++) {
+                            const float t = a - w[d + x];
+                            acc[d] = fmaf(t, t, acc[d]);
+                        }
+                    }
+                }
+            }
+
+#pragma unroll
+            for (int d = 0; d < SWIN; d++) cs[d][tid] = acc[d];
+            __syncthreads();
+
+            if (ref_ok) {
+#pragma unroll
+                for (int d = 0; d < SWIN; d++) {
+                    const float* c = &cs[d][tid];
+                    const float lo = (c[0] + c[1]) + (c[8] + c[9]);
+                    const float hi = (c[64] + c[65]) + (c[72] + c[73]);
+                    const float S = lo + hi;
+                    const int dx = d - RAD;
+                    const bool valid = vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
+                    uint32_t key = (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
+                    key = (valid && key < keymax) ? key : KEY_EMPTY;
+                    if (__any(key < list[MAXG - 1])) list_insert(list, key);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+}
 
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
@@ -57,6 +139,8 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     int xo[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) xo[j] = min(max(qx - RAD + j, 0), g.nx - 1);
+    // Interior cells read the window with four (unaligned) 16-byte loads instead.
+    const bool wide = (qx - RAD >= 0) && (qx - RAD + 15 <= g.nx - 1);
 
     const bool ref_ok = cx < TR && cy < TR && cz < TR && iz < g.az && iy < g.ay && ix < g.ax;
     const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
@@ -65,60 +149,13 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
 
-    for (int dzi = 0; dzi < SWIN; dzi++) {
-        const int dz = dzi - RAD;
-        const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
-        for (int dyi = 0; dyi < SWIN; dyi++) {
-            const int dy = dyi - RAD;
-            const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
-
-            float acc[SWIN];
-#pragma unroll
-            for (int d = 0; d < SWIN; d++) acc[d] = 0.0f;
-
-#pragma unroll
-            for (int z = 0; z < 4; z++) {
-                const int wz = min(max(qz + z + dz, 0), g.nz - 1);
-#pragma unroll
-                for (int y = 0; y < 4; y++) {
-                    const int wy = min(max(qy + y + dy, 0), g.ny - 1);
-                    const float* __restrict__ rowp = vol + (size_t)wz * sz + (size_t)wy * sy;
-                    float w[14];
-#pragma unroll
-                    for (int j = 0; j < 14; j++) w[j] = rowp[xo[j]];
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        const float a = A[(z * 4 + y) * 4 + x];
-#pragma unroll
-                        for (int d = 0; d < SWIN; d++) {
-                            const float t = a - w[d + x];
-                            acc[d] = fmaf(t, t, acc[d]);
-                        }
-                    }
-                }
-            }
-
-#pragma unroll
-            for (int d = 0; d < SWIN; d++) cs[d][tid] = acc[d];
-            __syncthreads();
-
-            if (ref_ok) {
-#pragma unroll
-                for (int d = 0; d < SWIN; d++) {
-                    const float* c = &cs[d][tid];
-                    const float lo = (c[0] + c[1]) + (c[8] + c[9]);
-                    const float hi = (c[64] + c[65]) + (c[72] + c[73]);
-                    const float S = lo + hi;
-                    const int dx = d - RAD;
-                    const bool valid = vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
-                    uint32_t key = (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
-                    key = (valid && key < keymax) ? key : KEY_EMPTY;
-                    if (__any(key < list[MAXG - 1])) list_insert(list, key);
-                }
-            }
-            __syncthreads();
-        }
-    }
+    // Wave-uniform choice: waves whose every cell lies in the x-interior use the wide-load body.
+    if (__all(wide))
+        bm_tile_loop<true>(vol, g, keymax, A, xo, qz, qy, qx, rz, ry, rx, ref_ok, tid, sy, sz, cs,
+                           list);
+    else
+        bm_tile_loop<false>(vol, g, keymax, A, xo, qz, qy, qx, rz, ry, rx, ref_ok, tid, sy, sz, cs,
+                            list);
 
     if (ref_ok) {
         uint32_t* out = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;

@@ -122,16 +122,71 @@ __device__ __forceinline__ void haar_inv(f16v& v) {
     }
 }
 
-// The transpose buffers are private to one wave and LDS executes a wave's instructions in issue
-// order, so between a buffer's writes and its (cross-lane) reads only the COMPILER must be kept
-// from reordering; no s_waitcnt or barrier is needed.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+// (In C++ `(f2)(a, b)` is a cast of a comma expression, not a vector literal.)
+__device__ __forceinline__ f2 mk2(float a, float b) {
+    f2 r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+
+// Two independent streams (.x, .y) through one packed-fp32 instruction stream: v_pk_fma_f32 etc.
+// do both components with one issue slot, which is what matters at one wave per SIMD.  Each
+// component is an ordinary IEEE fp32 operation, so results stay bit-identical to the oracle.
+__device__ __forceinline__ f2 chain4p(float c0, f2 v0, float c1, f2 v1, float c2, f2 v2, float c3,
+                                      f2 v3) {
+    f2 t = v0 * c0;
+    t = __builtin_elementwise_fma((f2)(c1), v1, t);
+    t = __builtin_elementwise_fma((f2)(c2), v2, t);
+    t = __builtin_elementwise_fma((f2)(c3), v3, t);
+    return t;
+}
+__device__ __forceinline__ void dct8_fwd2(const DctTable& T, f2 (&v)[8]) {
+    f2 s[4], d[4], o[8];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s[n] = v[n] + v[7 - n];
+        d[n] = v[n] - v[7 - n];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const float* c = T.d + u * 8;
+        o[u] = (u & 1) ? chain4p(c[0], d[0], c[1], d[1], c[2], d[2], c[3], d[3])
+                       : chain4p(c[0], s[0], c[1], s[1], c[2], s[2], c[3], s[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = o[u];
+}
+__device__ __forceinline__ void dct8_inv2(const DctTable& T, f2 (&v)[8]) {
+    f2 x[8];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const f2 e = chain4p(T.d[0 * 8 + n], v[0], T.d[2 * 8 + n], v[2], T.d[4 * 8 + n], v[4],
+                             T.d[6 * 8 + n], v[6]);
+        const f2 o = chain4p(T.d[1 * 8 + n], v[1], T.d[3 * 8 + n], v[3], T.d[5 * 8 + n], v[5],
+                             T.d[7 * 8 + n], v[7]);
+        x[n] = e + o;
+        x[7 - n] = e - o;
+    }
+#pragma unroll
+    for (int n = 0; n < 8; n++) v[n] = x[n];
+}
+
+// The transpose buffer is private to one wave and LDS executes a wave's instructions in issue
+// order, so between its writes and its (cross-lane) reads only the COMPILER must be kept from
+// reordering; no s_waitcnt or barrier is needed.
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
 
-__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p);
-    const float4 b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+__device__ __forceinline__ void load8p(const f2* p, f2 (&v)[8]) {
+    const f4* q = reinterpret_cast<const f4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const f4 t = q[i];
+        v[2 * i] = mk2(t.x, t.y);
+        v[2 * i + 1] = mk2(t.z, t.w);
+    }
 }
 
 // Issue the gather of one block (corner `src`) in layout L1 (hi = z, lo = x, regs y).
@@ -142,63 +197,39 @@ __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy
     for (int y = 0; y < 8; y++) v[y] = p[(size_t)y * sy];
 }
 
-// 3-D DCT of TWO blocks at once (independent streams a, b with their own transpose buffers, so
-// that the LDS round trips of one overlap the arithmetic of the other).  In: layout L1, out: L3.
-__device__ __forceinline__ void pair_fwd(const DctTable& T, float* ta, float* tb, int hi, int lo,
-                                         float (&a)[8], float (&b)[8]) {
-    dct8_fwd(T, a);                                             // along y
-    dct8_fwd(T, b);
+// 3-D DCT of TWO blocks at once (streams .x / .y; the transpose buffer holds float2 elements).
+// In: layout L1, out: L3.
+__device__ __forceinline__ void pair_fwd(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
+    dct8_fwd2(T, v);                                             // along y
 #pragma unroll
-    for (int y = 0; y < 8; y++) {                               // buffer [z][y][x]
-        ta[hi * 72 + y * 8 + lo] = a[y];
-        tb[hi * 72 + y * 8 + lo] = b[y];
-    }
+    for (int y = 0; y < 8; y++) tb[hi * 72 + y * 8 + lo] = v[y];    // buffer [z][y][x]
     cbar();
-    load8(ta + hi * 72 + lo * 8, a);                            // L2: hi = z, lo = y, regs x
-    load8(tb + hi * 72 + lo * 8, b);
+    load8p(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
     cbar();
-    dct8_fwd(T, a);                                             // along x
-    dct8_fwd(T, b);
+    dct8_fwd2(T, v);                                             // along x
 #pragma unroll
-    for (int x = 0; x < 8; x++) {                               // buffer [x][y][z]
-        ta[x * 64 + lo * 8 + hi] = a[x];
-        tb[x * 64 + lo * 8 + hi] = b[x];
-    }
+    for (int x = 0; x < 8; x++) tb[x * 64 + lo * 8 + hi] = v[x];    // buffer [x][y][z]
     cbar();
-    load8(ta + hi * 64 + lo * 8, a);                            // L3: hi = x, lo = y, regs z
-    load8(tb + hi * 64 + lo * 8, b);
+    load8p(tb + hi * 64 + lo * 8, v);                            // L3: hi = x, lo = y, regs z
     cbar();
-    dct8_fwd(T, a);                                             // along z
-    dct8_fwd(T, b);
+    dct8_fwd2(T, v);                                             // along z
 }
 
 // Inverse of pair_fwd: L3 spectra in, spatial blocks in layout L1 out.
-__device__ __forceinline__ void pair_inv(const DctTable& T, float* ta, float* tb, int hi, int lo,
-                                         float (&a)[8], float (&b)[8]) {
-    dct8_inv(T, a);                                             // along z (L3: hi = x, lo = y)
-    dct8_inv(T, b);
+__device__ __forceinline__ void pair_inv(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
+    dct8_inv2(T, v);                                             // along z (L3: hi = x, lo = y)
 #pragma unroll
-    for (int z = 0; z < 8; z++) {                               // buffer [z][y][x]
-        ta[z * 72 + lo * 8 + hi] = a[z];
-        tb[z * 72 + lo * 8 + hi] = b[z];
-    }
+    for (int z = 0; z < 8; z++) tb[z * 72 + lo * 8 + hi] = v[z];    // buffer [z][y][x]
     cbar();
-    load8(ta + hi * 72 + lo * 8, a);                            // L2: hi = z, lo = y, regs x
-    load8(tb + hi * 72 + lo * 8, b);
+    load8p(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
     cbar();
-    dct8_inv(T, a);                                             // along x
-    dct8_inv(T, b);
+    dct8_inv2(T, v);                                             // along x
 #pragma unroll
-    for (int x = 0; x < 8; x++) {                               // buffer [z][x][y]
-        ta[hi * 72 + x * 8 + lo] = a[x];
-        tb[hi * 72 + x * 8 + lo] = b[x];
-    }
+    for (int x = 0; x < 8; x++) tb[hi * 72 + x * 8 + lo] = v[x];    // buffer [z][x][y]
     cbar();
-    load8(ta + hi * 72 + lo * 8, a);                            // L1: hi = z, lo = x, regs y
-    load8(tb + hi * 72 + lo * 8, b);
+    load8p(tb + hi * 72 + lo * 8, v);                            // L1: hi = z, lo = x, regs y
     cbar();
-    dct8_inv(T, a);                                             // along y
-    dct8_inv(T, b);
+    dct8_inv2(T, v);                                             // along y
 }
 
 template <int K>
@@ -238,15 +269,33 @@ __device__ __forceinline__ void shrink_wiener(f16v (&spec)[8], f16v (&bspec)[8],
 }
 
 // Workgroup-wide spin lock in LDS (one lane of the wave takes it for the whole wave).
+// The CU's LDS serves the instructions of all its waves in arrival order, so the ring accesses
+// of the lock holder are ordered against the next holder's by the lock word itself: only the
+// compiler has to be kept from moving ring accesses across lock / unlock (no s_waitcnt, which
+// would also drain the wave's outstanding global loads and atomics).
 __device__ __forceinline__ void ring_lock(int* lock, int lane) {
+    cbar();
     if (lane == 0) {
-        while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+        int expected = 0;
+        while (!__hip_atomic_compare_exchange_strong(lock, &expected, 1, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            expected = 0;
+            __builtin_amdgcn_s_sleep(2);
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    cbar();
 }
 __device__ __forceinline__ void ring_unlock(int* lock, int lane) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicExch(lock, 0);
+    cbar();
+    if (lane == 0)
+        __hip_atomic_store(lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cbar();
+}
+// Workgroup barrier that waits for this wave's LDS operations only (a plain __syncthreads()
+// also waits for outstanding global atomics, whose completion nobody in the kernel needs).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 struct TileGeom {
@@ -261,8 +310,7 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
                                               const uint32_t* __restrict__ kk, int rz, int ry,
                                               int rx, const TileGeom& tg, size_t sy, size_t sz,
                                               const DctTable& T, const float (&win)[8], float thr,
-                                              float sigma2, float* rnum, float* rden, float* ta,
-                                              float* tb, int* lock, int lane
+                                              float sigma2, f2* ring, f2* tb, int* lock, int lane
 #ifdef EXABM4D_STAMPS
                                               , unsigned long long (&st)[16]
 #endif
@@ -293,6 +341,7 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
     };
     const int kstep = WIENER ? 1 : 2;
     float a[8], b[8], na[8] = {}, nb[8] = {};
+    f2 v2[8];
     {
         const size_t c0 = corner_of(0);
         gather8(noisy + c0, sy, sz, hi, lo, a);
@@ -311,19 +360,21 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
             else
                 gather8(noisy + corner_of(kn + 1), sy, sz, hi, lo, nb);
         }
-        pair_fwd(T, ta, tb, hi, lo, a, b);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+        pair_fwd(T, tb, hi, lo, v2);
         if (WIENER) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                spec[j][k] = a[j];
-                bspec[j][k] = b[j];
+                spec[j][k] = v2[j].x;
+                bspec[j][k] = v2[j].y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) spec[j][k] = a[j];
+            for (int j = 0; j < 8; j++) spec[j][k] = v2[j].x;
             if (K > 1) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) spec[j][k + 1] = b[j];
+                for (int j = 0; j < 8; j++) spec[j][k + 1] = v2[j].y;
             }
         }
 #pragma unroll
@@ -373,16 +424,13 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
     for (int k = 0; k < K; k += 2) {
         const int k2 = (k + 1 < K) ? k + 1 : k;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            a[j] = spec[j][k];
-            b[j] = spec[j][k2];
-        }
-        pair_inv(T, ta, tb, hi, lo, a, b);
+        for (int j = 0; j < 8; j++) v2[j] = mk2(spec[j][k], spec[j][k2]);
+        pair_inv(T, tb, hi, lo, v2);
 #pragma unroll
-        for (int j = 0; j < 8; j++) spec[j][k] = a[j];
+        for (int j = 0; j < 8; j++) spec[j][k] = v2[j].x;
         if (k2 != k) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) spec[j][k2] = b[j];
+            for (int j = 0; j < 8; j++) spec[j][k2] = v2[j].y;
         }
     }
 
@@ -403,17 +451,12 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
         int slot = (rz + dz + 5) % NPL + hi;
         slot -= slot >= NPL ? NPL : 0;
         const int off = slot * PS + (ry + dy - tg.y0) * REG + (rx + dx - tg.x0) + lo;
-        float an[8], ad[8];
+        f2 acc[8];
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-            an[y] = rnum[off + y * REG];
-            ad[y] = rden[off + y * REG];
-        }
+        for (int y = 0; y < 8; y++) acc[y] = ring[off + y * REG];
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-            rnum[off + y * REG] = an[y] + ww[y] * spec[y][k];
-            rden[off + y * REG] = ad[y] + ww[y];
-        }
+        for (int y = 0; y < 8; y++)
+            ring[off + y * REG] = acc[y] + mk2(ww[y] * spec[y][k], ww[y]);
     }
     ring_unlock(lock, lane);
     STAMP(t5);
@@ -422,25 +465,23 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
 
 // Move ring planes [zlo, zhi) to global memory (float atomics: neighbouring tiles overlap) and
 // zero them.  Whole workgroup.
-__device__ __forceinline__ void flush_planes(float* rnum, float* rden, float* __restrict__ num,
+__device__ __forceinline__ void flush_planes(f2* ring, float* __restrict__ num,
                                              float* __restrict__ den, int zlo, int zhi,
-                                             const TileGeom& tg, const VolGeom& g, int nthreads) {
-    const int nplanes = zhi - zlo;
-    for (int i = threadIdx.x; i < nplanes * REG * REG; i += nthreads) {
-        const int pl = i / (REG * REG), rem = i - pl * (REG * REG);
-        const int z = zlo + pl;
+                                             const TileGeom& tg, const VolGeom& g, int nwaves) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int z = zlo + wave; z < zhi; z += nwaves) {          // one plane per wave
         const int slot = (z + 5) % NPL;
-        const int o = slot * PS + rem;
-        const float d = rden[o];
-        if (d != 0.0f) {
-            const int ryy = rem / REG, rxx = rem - ryy * REG;
-            const int y = tg.y0 + ryy, x = tg.x0 + rxx;
-            // d != 0 implies a block covered this voxel, so it lies inside the volume
-            const size_t go = ((size_t)z * g.ny + y) * g.nx + x;
-            atomicAdd(num + go, rnum[o]);
-            atomicAdd(den + go, d);
-            rnum[o] = 0.0f;
-            rden[o] = 0.0f;
+        f2* plane = ring + slot * PS;
+        for (int rem = lane; rem < REG * REG; rem += 64) {
+            const f2 nd = plane[rem];
+            if (nd.y != 0.0f) {
+                const int ryy = rem / REG, rxx = rem - ryy * REG;
+                // den != 0 implies a block covered this voxel, so it lies inside the volume
+                const size_t go = ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx);
+                atomicAdd(num + go, nd.x);
+                atomicAdd(den + go, nd.y);
+                plane[rem] = mk2(0.0f, 0.0f);
+            }
         }
     }
 }
@@ -452,11 +493,9 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ den_all, int tiles_x,
     int layers_per_chunk) {
     extern __shared__ __align__(16) float lds[];
-    float* rnum = lds;
-    float* rden = lds + NPL * PS;
+    f2* ring = reinterpret_cast<f2*>(lds);                 // [NPL][PS] (num, den) pairs
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float* ta = lds + 2 * NPL * PS + wave * 2 * TBUF;
-    float* tb = ta + TBUF;
+    f2* tb = reinterpret_cast<f2*>(lds + 2 * NPL * PS + wave * 2 * TBUF);
     int* lock = reinterpret_cast<int*>(lds + 2 * NPL * PS + NW * 2 * TBUF);
 
     const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
@@ -500,9 +539,9 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
         const int z0 = grid_pos(iz, g.az, g.nz);
         STAMP(tf0);
         if (z0 - RAD > base) {
-            flush_planes(rnum, rden, num, den, base, z0 - RAD, tg, g, NW * 64);
+            flush_planes(ring, num, den, base, z0 - RAD, tg, g, NW);
             base = z0 - RAD;
-            __syncthreads();
+            lds_barrier();
         }
         STAMP(tf1);
         STAMP_ADD(5, tf0, tf1);
@@ -512,18 +551,18 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
             const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
             process_group<WIENER>(noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2,
-                                  rnum, rden, ta, tb, lock, lane
+                                  ring, tb, lock, lane
 #ifdef EXABM4D_STAMPS
                                   , st
 #endif
                                   );
         }
         STAMP(tb0);
-        __syncthreads();
+        lds_barrier();
         STAMP(tb1);
         STAMP_ADD(6, tb0, tb1);
     }
-    flush_planes(rnum, rden, num, den, base, base + NPL, tg, g, NW * 64);
+    flush_planes(ring, num, den, base, base + NPL, tg, g, NW);
 #ifdef EXABM4D_STAMPS
     st[7] = stamp() - tk0;
     if (lane == 0)
