@@ -79,6 +79,20 @@ def synth_u16(shape, seed):
     return out
 
 
+def measured_traffic(kernel, shape):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/traffic_latest.json: FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction),
+    or None when no profile of this volume shape is on file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            t = json.load(f)
+        if list(t["volume"]) == list(shape):
+            return t["bytes_per_launch"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(sample_edge, seed):
     """CPU oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
     from oracle import bm4d_oracle
@@ -201,7 +215,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(dom, shape),
                 "algorithmic_bytes_per_voxel": ALGO_BYTES_PER_VOXEL[dom],
                 "avg_ms": kern[dom],
             },
