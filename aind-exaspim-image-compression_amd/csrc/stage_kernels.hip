@@ -49,7 +49,9 @@ constexpr int TILE_R = 4;                 // grid points per tile edge in y and 
 constexpr int REG = 30;                   // ring region edge: 12 (3 steps) + 8 (block) + 2*5
 constexpr int PS = 904;                   // ring plane stride: 900 padded to 8 (mod 32)
 constexpr int NPL = 18;                   // ring planes: z0-5 .. z0+12
-constexpr int TBUF = 576;                 // per-wave transpose buffer (8 planes x 72 floats)
+constexpr int TBUF = 640;                 // per-wave transpose buffer: [8][8][8] float2, strides below
+constexpr int TSI = 80, TSJ = 10;         // (found by enumeration) make the b64 writes and b128 reads
+                                          // of all four transposes bank-conflict-free but one 2-way write
 constexpr float HAAR_C = 0.70710678118654752440f;
 
 __device__ __forceinline__ float chain4(float c0, float v0, float c1, float v1, float c2, float v2,
@@ -202,15 +204,15 @@ __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy
 __device__ __forceinline__ void pair_fwd(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_fwd2(T, v);                                             // along y
 #pragma unroll
-    for (int y = 0; y < 8; y++) tb[hi * 72 + y * 8 + lo] = v[y];    // buffer [z][y][x]
+    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = v[y];  // buffer [z][y][x]
     cbar();
-    load8p(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
+    load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
     cbar();
     dct8_fwd2(T, v);                                             // along x
 #pragma unroll
-    for (int x = 0; x < 8; x++) tb[x * 64 + lo * 8 + hi] = v[x];    // buffer [x][y][z]
+    for (int x = 0; x < 8; x++) tb[x * TSI + lo * TSJ + hi] = v[x];  // buffer [x][y][z]
     cbar();
-    load8p(tb + hi * 64 + lo * 8, v);                            // L3: hi = x, lo = y, regs z
+    load8p(tb + hi * TSI + lo * TSJ, v);                         // L3: hi = x, lo = y, regs z
     cbar();
     dct8_fwd2(T, v);                                             // along z
 }
@@ -219,15 +221,15 @@ __device__ __forceinline__ void pair_fwd(const DctTable& T, f2* tb, int hi, int 
 __device__ __forceinline__ void pair_inv(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_inv2(T, v);                                             // along z (L3: hi = x, lo = y)
 #pragma unroll
-    for (int z = 0; z < 8; z++) tb[z * 72 + lo * 8 + hi] = v[z];    // buffer [z][y][x]
+    for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = v[z];  // buffer [z][y][x]
     cbar();
-    load8p(tb + hi * 72 + lo * 8, v);                            // L2: hi = z, lo = y, regs x
+    load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
     cbar();
     dct8_inv2(T, v);                                             // along x
 #pragma unroll
-    for (int x = 0; x < 8; x++) tb[hi * 72 + x * 8 + lo] = v[x];    // buffer [z][x][y]
+    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = v[x];  // buffer [z][x][y]
     cbar();
-    load8p(tb + hi * 72 + lo * 8, v);                            // L1: hi = z, lo = x, regs y
+    load8p(tb + hi * TSI + lo * TSJ, v);                         // L1: hi = z, lo = x, regs y
     cbar();
     dct8_inv2(T, v);                                             // along y
 }
