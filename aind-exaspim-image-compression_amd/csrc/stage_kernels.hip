@@ -307,12 +307,13 @@ struct TileGeom {
 
 // One wave, one group.
 template <bool WIENER>
-__device__ __forceinline__ void process_group(const float* __restrict__ noisy,
+__device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
                                               const float* __restrict__ basic,
                                               const uint32_t* __restrict__ kk, int rz, int ry,
                                               int rx, const TileGeom& tg, size_t sy, size_t sz,
                                               const DctTable& T, const float (&win)[8], float thr,
-                                              float sigma2, f2* ring, f2* tb, int* lock, int lane
+                                              float sigma2, f2* ring, f2* tb, int* lock, int layer,
+                                              int target, int lane
 #ifdef EXABM4D_STAMPS
                                               , unsigned long long (&st)[16]
 #endif
@@ -443,6 +444,12 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
     // are added correctly one after the other.
     STAMP(t3);
     STAMP_ADD(2, t2, t3);
+    // lock[0] = ring lock, lock[1] = groups aggregated so far, lock[2] = layers whose entry
+    // flush is complete.  This layer's retired planes must have left the ring first.
+    if (lane == 0) {
+        while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
+            __builtin_amdgcn_s_sleep(4);
+    }
     ring_lock(lock, lane);
     STAMP(t4);
     STAMP_ADD(3, t3, t4);
@@ -463,6 +470,13 @@ __device__ __forceinline__ void process_group(const float* __restrict__ noisy,
     ring_unlock(lock, lane);
     STAMP(t5);
     STAMP_ADD(4, t4, t5);
+    // The wave that aggregates the layer's last group closes the layer (it flushes the planes
+    // the next layer retires); everybody else runs ahead into the next layer's transforms.
+    int closer = 0;
+    if (lane == 0)
+        closer = (__hip_atomic_fetch_add(lock + 1, 1, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == target) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(closer) != 0;
 }
 
 // Move ring planes [zlo, zhi) to global memory (float atomics: neighbouring tiles overlap) and
@@ -479,6 +493,26 @@ __device__ __forceinline__ void flush_planes(f2* ring, float* __restrict__ num,
             if (nd.y != 0.0f) {
                 const int ryy = rem / REG, rxx = rem - ryy * REG;
                 // den != 0 implies a block covered this voxel, so it lies inside the volume
+                const size_t go = ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx);
+                atomicAdd(num + go, nd.x);
+                atomicAdd(den + go, nd.y);
+                plane[rem] = mk2(0.0f, 0.0f);
+            }
+        }
+    }
+}
+
+// Same, by ONE wave (the wave that closes a layer).
+__device__ __forceinline__ void flush_planes_wave(f2* ring, float* __restrict__ num,
+                                                  float* __restrict__ den, int zlo, int zhi,
+                                                  const TileGeom& tg, const VolGeom& g, int lane) {
+    for (int z = zlo; z < zhi; z++) {
+        const int slot = (z + 5) % NPL;
+        f2* plane = ring + slot * PS;
+        for (int rem = lane; rem < REG * REG; rem += 64) {
+            const f2 nd = plane[rem];
+            if (nd.y != 0.0f) {
+                const int ryy = rem / REG, rxx = rem - ryy * REG;
                 const size_t go = ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx);
                 atomicAdd(num + go, nd.x);
                 atomicAdd(den + go, nd.y);
@@ -521,7 +555,11 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     const int ize = min(g.gz, izb + layers_per_chunk);
 
     for (int i = threadIdx.x; i < 2 * NPL * PS; i += NW * 64) lds[i] = 0.0f;
-    if (threadIdx.x == 0) *lock = 0;
+    if (threadIdx.x == 0) {
+        lock[0] = 0;   // ring lock
+        lock[1] = 0;   // groups aggregated
+        lock[2] = 1;   // layer 0 needs no entry flush
+    }
 
     // aggregation window of this lane in layout L1 (lane = (z,x), regs y)
     float win[8];
@@ -532,39 +570,51 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     }
     __syncthreads();
 
-    int base = grid_pos(izb, g.az, g.nz) - RAD;   // lowest plane held by the ring
 #ifdef EXABM4D_STAMPS
     unsigned long long st[16] = {};
     const unsigned long long tk0 = stamp();
 #endif
+    // No workgroup barrier between layers: a wave only has to wait, right before it aggregates a
+    // group of layer L, until the planes that layer L retires have been flushed -- which the wave
+    // closing layer L-1 does.  Waves that finish a layer early start the next layer's transforms.
     for (int iz = izb; iz < ize; iz++) {
+        const int layer = iz - izb;
         const int z0 = grid_pos(iz, g.az, g.nz);
-        STAMP(tf0);
-        if (z0 - RAD > base) {
-            flush_planes(ring, num, den, base, z0 - RAD, tg, g, NW);
-            base = z0 - RAD;
-            lds_barrier();
-        }
-        STAMP(tf1);
-        STAMP_ADD(5, tf0, tf1);
         for (int r = wave; r < nrefs; r += NW) {
             const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
             const int iy = iy0 + jy, ix = ix0 + jx;
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
             const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
-            process_group<WIENER>(noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2,
-                                  ring, tb, lock, lane
+            const bool closer = process_group<WIENER>(noisy, basic, kk, z0, ry, rx, tg, sy, sz, T,
+                                                      win, thr, sigma2, ring, tb, lock, layer,
+                                                      nrefs * (layer + 1), lane
 #ifdef EXABM4D_STAMPS
-                                  , st
+                                                      , st
 #endif
-                                  );
+            );
+            if (closer) {
+                STAMP(tf0);
+                if (iz + 1 < ize) {
+                    const int zn = grid_pos(iz + 1, g.az, g.nz);
+                    flush_planes_wave(ring, num, den, z0 - RAD, zn - RAD, tg, g, lane);
+                }
+                cbar();
+                if (lane == 0)
+                    __hip_atomic_store(lock + 2, layer + 2, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                STAMP(tf1);
+                STAMP_ADD(5, tf0, tf1);
+            }
         }
-        STAMP(tb0);
-        lds_barrier();
-        STAMP(tb1);
-        STAMP_ADD(6, tb0, tb1);
     }
-    flush_planes(ring, num, den, base, base + NPL, tg, g, NW);
+    STAMP(tb0);
+    __syncthreads();
+    STAMP(tb1);
+    STAMP_ADD(6, tb0, tb1);
+    if (ize > izb) {
+        const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
+        flush_planes(ring, num, den, base, base + NPL, tg, g, NW);
+    }
 #ifdef EXABM4D_STAMPS
     st[7] = stamp() - tk0;
     if (lane == 0)
