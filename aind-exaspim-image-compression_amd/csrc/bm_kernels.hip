@@ -30,20 +30,26 @@ constexpr int PROWS = 4 * (TC - 1) + 3 + NE;   // 37 staged rows: 4*cy + y + e
 constexpr int PCOLS = 4 * (TC - 1) + 16;       // 44 staged columns: 4*cx + 0..15
 constexpr int PSTR = 56;     // row stride in floats: 8 (mod 16) makes the b128 window reads
                              // of lanes (cy,cx) conflict-free
-constexpr int PBUF = PROWS * PSTR;
+constexpr int PCH = PSTR / 4;                   // 16-byte chunks per staged row (14, 11 used)
+constexpr int NDMA = (PROWS * PCH + 63) / 64;   // LDS-DMA instructions per plane (9 x 1 KiB)
+constexpr int PBUF = NDMA * 256;                // floats per plane buffer (2304)
+constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
 
 // Each WAVE (= one z-layer of 8x8 cells) streams the candidate planes it needs through its own
-// LDS buffer: for a fixed dz and a pass of NE dy values, plane z+dz of the volume (37 rows x 44
-// columns around the tile) is staged once and serves all 4 x NE x 11 (row, dy, dx) combinations
-// of every cell of the wave.  The search window is therefore read from L2/HBM 2 x 11 times per
-// plane instead of 121 x 4 times per row (measured before: 1.8 TB of fabric traffic per
-// 1024^3 launch, 7 TB/s -- the kernel was bandwidth-bound on re-reads).
+// pair of LDS buffers: for a fixed dz and a pass of NE dy values, plane z+dz of the volume
+// (37 rows x 44 columns around the tile) is staged once and serves all 4 x NE x 11 (row, dy, dx)
+// combinations of every cell of the wave.  Interior tiles stage with LDS-DMA
+// (global_load_lds_dwordx4: no registers, one step ahead of the arithmetic); tiles at an x edge
+// of the volume stage synchronously with per-element clamping.  The search window is therefore
+// read from L2/HBM 2 x 11 times per plane instead of 121 x 4 times per row (measured before:
+// 1.8 TB of fabric traffic per 1024^3 launch at 7 TB/s -- bandwidth-bound on re-reads).
+// The cell-sum exchange buffer aliases the waves' current plane buffers (each wave publishes the
+// sums of its own 64 cells in its own buffer once its reads of the plane are done).
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
                                                       int tiles_x) {
-    __shared__ __align__(16) float cs[SWIN][TC * TC * TC];
-    __shared__ __align__(16) float pbuf_all[TC][PBUF];
+    __shared__ __align__(16) float pbuf_all[TC][2][PBUF];
 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
@@ -54,7 +60,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const int cx = tid & 7, cy = (tid >> 3) & 7, cz = tid >> 6;      // cz == wave index
     const int lane = tid & 63;
     const int ix = TR * tx + cx, iy = TR * ty + cy, iz = TR * tz + cz;  // cell == ref index
-    float* pbuf = pbuf_all[cz];
 
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
@@ -73,121 +78,157 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
 
-    for (int dzi = 0; dzi < SWIN; dzi++) {
-        const int dz = dzi - RAD;
-        const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
-        for (int pass = 0; pass < 2; pass++) {
-            const int dylo = pass == 0 ? -RAD : 1;
+    auto step_plane = [&](int step, int& dylo) -> const float* {
+        const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
+        dylo = pass == 0 ? -RAD : 1;
+        const int pz = min(max(Z0 + z + dz, 0), g.nz - 1);
+        return vol + (size_t)pz * sz;
+    };
+    // LDS-DMA of one plane into buffer `dst`: instruction i writes floats [256 i, 256 i + 256)
+    // linearly, lane l the 16 bytes at chunk p = 64 i + l = (row p / 14, column chunk p % 14);
+    // chunks beyond column 10 or row 36 are padding and re-read a valid address.
+    auto issue_dma = [&](int step, float* dst) {
+        int dylo;
+        const float* plane = step_plane(step, dylo);
+        int l = lane;
+        asm volatile("" : "+v"(l));          // keeps the 9 (row, column) pairs out of registers
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) {
+            const int p = 64 * i + l;
+            const int r = min(p / PCH, PROWS - 1), q = min(p % PCH, PCOLS / 4 - 1);
+            const int yy = min(max(Y0 + dylo + r, 0), g.ny - 1);
+            const float* src = plane + (size_t)yy * sy + (X0 + 4 * q);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
+        }
+    };
+    auto stage_edge = [&](int step, float* dst) {               // edge tiles: clamp per element
+        int dylo;
+        const float* plane = step_plane(step, dylo);
+        for (int c = lane; c < PROWS * PCOLS; c += 64) {
+            const int r = c / PCOLS, q = c - r * PCOLS;
+            const int yy = min(max(Y0 + dylo + r, 0), g.ny - 1);
+            const int xx = min(max(X0 + q, 0), g.nx - 1);
+            dst[r * PSTR + q] = plane[(size_t)yy * sy + xx];
+        }
+    };
 
-            float acc[NE][SWIN];
+    if (xin)
+        issue_dma(0, pbuf_all[cz][0]);
+    else
+        stage_edge(0, pbuf_all[cz][0]);
+
+    float acc[NE][SWIN];
 #pragma unroll
-            for (int e = 0; e < NE; e++)
+    for (int e = 0; e < NE; e++)
 #pragma unroll
-                for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
+        for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
 
 #pragma unroll 1
-            for (int z = 0; z < 4; z++) {
-                // ---- stage plane Z0 + z + dz (clamped) into this wave's buffer -------------
-                const int pz = min(max(Z0 + z + dz, 0), g.nz - 1);
-                const float* __restrict__ plane = vol + (size_t)pz * sz;
-                __builtin_amdgcn_wave_barrier();
-                if (xin) {
-                    for (int c = lane; c < PROWS * (PCOLS / 4); c += 64) {
-                        const int r = c / (PCOLS / 4), q = c - r * (PCOLS / 4);
-                        const int yy = min(max(Y0 + dylo + r, 0), g.ny - 1);
-                        const float4u t4 = *reinterpret_cast<const float4u*>(
-                            plane + (size_t)yy * sy + (X0 + 4 * q));
-                        *reinterpret_cast<float4*>(pbuf + r * PSTR + 4 * q) =
-                            make_float4(t4.x, t4.y, t4.z, t4.w);
-                    }
-                } else {
-                    for (int c = lane; c < PROWS * PCOLS; c += 64) {
-                        const int r = c / PCOLS, q = c - r * PCOLS;
-                        const int yy = min(max(Y0 + dylo + r, 0), g.ny - 1);
-                        const int xx = min(max(X0 + q, 0), g.nx - 1);
-                        pbuf[r * PSTR + q] = plane[(size_t)yy * sy + xx];
-                    }
+    for (int step = 0; step < NSTEP; step++) {
+        const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
+        const int dylo = pass == 0 ? -RAD : 1;
+        float* cur = pbuf_all[cz][step & 1];
+        float* nxt = pbuf_all[cz][(step + 1) & 1];
+
+        // this step's plane has landed (DMA counts in vmcnt) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and the next one starts flying while this one is consumed
+        if (xin && step + 1 < NSTEP) issue_dma(step + 1, nxt);
+
+        // own cell plane z (16 values; L1-resident after the first pass)
+        float A[16];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const float4u t4 = *reinterpret_cast<const float4u*>(
+                vol + (size_t)(qz + z) * sz + (size_t)(qy + y) * sy + qx);
+            A[4 * y] = t4.x;
+            A[4 * y + 1] = t4.y;
+            A[4 * y + 2] = t4.z;
+            A[4 * y + 3] = t4.w;
+        }
+
+        // ---- accumulate: row rp = y + e of the cell's window -----------------------------------
+        {
+            const float* wrow = cur + (4 * cy) * PSTR + 4 * cx;
+            float4 wq[4], wn[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wq[j] = *reinterpret_cast<const float4*>(wrow + 4 * j);
+#pragma unroll
+            for (int rp = 0; rp < 3 + NE; rp++) {
+                // one-row lookahead; the fence keeps hipcc from hoisting all nine rows' loads
+                // (and their 144 registers) to the top of the plane
+                if (rp + 1 < 3 + NE) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        wn[j] = *reinterpret_cast<const float4*>(wrow + (rp + 1) * PSTR + 4 * j);
                 }
-                // own cell plane z (16 values; L1-resident after the first pass)
-                float A[16];
+                asm volatile("" ::: "memory");
+                const float w[16] = {wq[0].x, wq[0].y, wq[0].z, wq[0].w, wq[1].x, wq[1].y,
+                                     wq[1].z, wq[1].w, wq[2].x, wq[2].y, wq[2].z, wq[2].w,
+                                     wq[3].x, wq[3].y, wq[3].z, wq[3].w};
 #pragma unroll
                 for (int y = 0; y < 4; y++) {
-                    const float4u t4 = *reinterpret_cast<const float4u*>(
-                        vol + (size_t)(qz + z) * sz + (size_t)(qy + y) * sy + qx);
-                    A[4 * y] = t4.x;
-                    A[4 * y + 1] = t4.y;
-                    A[4 * y + 2] = t4.z;
-                    A[4 * y + 3] = t4.w;
-                }
-                // the buffer is private to the wave and LDS is in order: compiler fence only
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-
-                // ---- accumulate: row rp = y + e of the cell's window ---------------------------
-                const float* wrow = pbuf + (4 * cy) * PSTR + 4 * cx;
-                float4 wq[4], wn[4];
+                    const int e = rp - y;
+                    if (e >= 0 && e < NE) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) wq[j] = *reinterpret_cast<const float4*>(wrow + 4 * j);
+                        for (int x = 0; x < 4; x++) {
+                            const float a = A[4 * y + x];
 #pragma unroll
-                for (int rp = 0; rp < 3 + NE; rp++) {
-                    // one-row lookahead; the fence keeps hipcc from hoisting all nine rows' loads
-                    // (and their 144 registers) to the top of the plane
-                    if (rp + 1 < 3 + NE) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            wn[j] = *reinterpret_cast<const float4*>(wrow + (rp + 1) * PSTR + 4 * j);
-                    }
-                    asm volatile("" ::: "memory");
-                    const float w[16] = {wq[0].x, wq[0].y, wq[0].z, wq[0].w, wq[1].x, wq[1].y,
-                                         wq[1].z, wq[1].w, wq[2].x, wq[2].y, wq[2].z, wq[2].w,
-                                         wq[3].x, wq[3].y, wq[3].z, wq[3].w};
-#pragma unroll
-                    for (int y = 0; y < 4; y++) {
-                        const int e = rp - y;
-                        if (e >= 0 && e < NE) {
-#pragma unroll
-                            for (int x = 0; x < 4; x++) {
-                                const float a = A[4 * y + x];
-#pragma unroll
-                                for (int d = 0; d < SWIN; d++) {
-                                    const float t = a - w[d + x];
-                                    acc[e][d] = fmaf(t, t, acc[e][d]);
-                                }
+                            for (int d = 0; d < SWIN; d++) {
+                                const float t = a - w[d + x];
+                                acc[e][d] = fmaf(t, t, acc[e][d]);
                             }
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) wq[j] = wn[j];
                 }
-                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < 4; j++) wq[j] = wn[j];
             }
+        }
+        asm volatile("" ::: "memory");
 
+        if (z == 3) {
             // ---- cell sums -> LDS -> reference lanes: combine 8 cells, build keys, top-16 ------
+            // exchange slot of cell (wave w, local l), displacement d: pbuf_all[w][cur][64 d + l]
+            const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
+            float* mine = cur + lane;
+            const float* lo_w = cur + lane;                                  // cells of wave cz
+            const float* hi_w = pbuf_all[min(cz + 1, TC - 1)][step & 1] + lane;  // wave cz + 1
 #pragma unroll
             for (int e = 0; e < NE; e++) {
                 const int dy = dylo + e;
-                if (dy > RAD) break;                       // dy = 6 of the second pass
-                const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
+                if (dy <= RAD) {                           // dy = 6 of the second pass is a dummy
+                    const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
 #pragma unroll
-                for (int d = 0; d < SWIN; d++) cs[d][tid] = acc[e][d];
-                __syncthreads();
-                if (ref_ok) {
+                    for (int d = 0; d < SWIN; d++) mine[64 * d] = acc[e][d];
+                    __syncthreads();
+                    if (ref_ok) {
 #pragma unroll
-                    for (int d = 0; d < SWIN; d++) {
-                        const float* c = &cs[d][tid];
-                        const float lo = (c[0] + c[1]) + (c[8] + c[9]);
-                        const float hi = (c[64] + c[65]) + (c[72] + c[73]);
-                        const float S = lo + hi;
-                        const int dx = d - RAD;
-                        const bool valid = vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
-                        uint32_t key = (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
-                        key = (valid && key < keymax) ? key : KEY_EMPTY;
-                        if (__any(key < list[MAXG - 1])) list_insert(list, key);
+                        for (int d = 0; d < SWIN; d++) {
+                            const float* c0 = lo_w + 64 * d;
+                            const float* c1 = hi_w + 64 * d;
+                            const float lo = (c0[0] + c0[1]) + (c0[8] + c0[9]);
+                            const float hi = (c1[0] + c1[1]) + (c1[8] + c1[9]);
+                            const float S = lo + hi;
+                            const int dx = d - RAD;
+                            const bool valid = vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
+                            uint32_t key =
+                                (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
+                            key = (valid && key < keymax) ? key : KEY_EMPTY;
+                            if (__any(key < list[MAXG - 1])) list_insert(list, key);
+                        }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
+#pragma unroll
+                for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
             }
         }
+
+        // edge tiles stage the next plane synchronously (all reads of `nxt` are long done)
+        if (!xin && step + 1 < NSTEP) stage_edge(step + 1, nxt);
     }
 
     if (ref_ok) {
