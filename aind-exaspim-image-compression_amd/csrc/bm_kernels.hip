@@ -134,9 +134,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 
         // this step's plane has landed (DMA counts in vmcnt) ...
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ... and the next one starts flying while this one is consumed
-        if (xin && step + 1 < NSTEP) issue_dma(step + 1, nxt);
-
         // own cell plane z (16 values; L1-resident after the first pass)
         float A[16];
 #pragma unroll
@@ -148,6 +145,11 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             A[4 * y + 2] = t4.z;
             A[4 * y + 3] = t4.w;
         }
+        // ... and the next plane starts flying while this one is consumed.  The A loads are
+        // drained first: vmcnt retires in order and hipcc waits vmcnt(0) for A after the
+        // (conditional) DMA block, which would expose the whole DMA latency every step.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (xin && step + 1 < NSTEP) issue_dma(step + 1, nxt);
 
         // ---- accumulate: row rp = y + e of the cell's window -----------------------------------
         {
@@ -196,35 +198,45 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             float* mine = cur + lane;
             const float* lo_w = cur + lane;                                  // cells of wave cz
             const float* hi_w = pbuf_all[min(cz + 1, TC - 1)][step & 1] + lane;  // wave cz + 1
+            // NE / 2 dy values per round (33 sums per cell fit the 36 slots of a plane buffer):
+            // two barrier pairs per pass instead of six.
 #pragma unroll
-            for (int e = 0; e < NE; e++) {
-                const int dy = dylo + e;
-                if (dy <= RAD) {                           // dy = 6 of the second pass is a dummy
-                    const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
+            for (int e0 = 0; e0 < NE; e0 += NE / 2) {
 #pragma unroll
-                    for (int d = 0; d < SWIN; d++) mine[64 * d] = acc[e][d];
-                    __syncthreads();
-                    if (ref_ok) {
+                for (int e = e0; e < e0 + NE / 2; e++)
 #pragma unroll
-                        for (int d = 0; d < SWIN; d++) {
-                            const float* c0 = lo_w + 64 * d;
-                            const float* c1 = hi_w + 64 * d;
-                            const float lo = (c0[0] + c0[1]) + (c0[8] + c0[9]);
-                            const float hi = (c1[0] + c1[1]) + (c1[8] + c1[9]);
-                            const float S = lo + hi;
-                            const int dx = d - RAD;
-                            const bool valid = vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
-                            uint32_t key =
-                                (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
-                            key = (valid && key < keymax) ? key : KEY_EMPTY;
-                            if (__any(key < list[MAXG - 1])) list_insert(list, key);
+                    for (int d = 0; d < SWIN; d++) mine[64 * ((e - e0) * SWIN + d)] = acc[e][d];
+                __syncthreads();
+                if (ref_ok) {
+#pragma unroll
+                    for (int e = e0; e < e0 + NE / 2; e++) {
+                        const int dy = dylo + e;
+                        if (dy <= RAD) {                   // dy = 6 of the second pass is a dummy
+                            const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
+#pragma unroll
+                            for (int d = 0; d < SWIN; d++) {
+                                const float* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
+                                const float* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
+                                const float lo = (c0[0] + c0[1]) + (c0[8] + c0[9]);
+                                const float hi = (c1[0] + c1[1]) + (c1[8] + c1[9]);
+                                const float S = lo + hi;
+                                const int dx = d - RAD;
+                                const bool valid =
+                                    vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
+                                uint32_t key =
+                                    (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
+                                key = (valid && key < keymax) ? key : KEY_EMPTY;
+                                if (__any(key < list[MAXG - 1])) list_insert(list, key);
+                            }
                         }
                     }
-                    __syncthreads();
                 }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e++)
 #pragma unroll
                 for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
-            }
         }
 
         // edge tiles stage the next plane synchronously (all reads of `nxt` are long done)
