@@ -234,43 +234,91 @@ __device__ __forceinline__ void pair_inv(const DctTable& T, f2* tb, int hi, int 
     dct8_inv2(T, v);                                             // along y
 }
 
+typedef float f32v __attribute__((ext_vector_type(32)));
+
+// Packed Haar along the group axis: v[k] holds two independent sequences in .x / .y.
 template <int K>
-__device__ __forceinline__ void shrink_ht(f16v (&spec)[8], float thr, int& nnz) {
+__device__ __forceinline__ void haar_fwd2(f2 (&v)[MAXG]) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        f16v s = spec[j];
-        haar_fwd<K>(s);
+    for (int len = K; len > 1; len >>= 1) {
+        const int half = len >> 1;
+        f2 t[MAXG];
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const bool keep = fabsf(s[k]) >= thr;
-            nnz += keep ? 1 : 0;
-            s[k] = keep ? s[k] : 0.0f;
+        for (int i = 0; i < half; i++) {
+            t[i] = (v[2 * i] + v[2 * i + 1]) * HAAR_C;
+            t[half + i] = (v[2 * i] - v[2 * i + 1]) * HAAR_C;
         }
-        haar_inv<K>(s);
-        spec[j] = s;
+#pragma unroll
+        for (int i = 0; i < len; i++) v[i] = t[i];
     }
 }
+template <int K>
+__device__ __forceinline__ void haar_inv2(f2 (&v)[MAXG]) {
+#pragma unroll
+    for (int len = 1; len < K; len <<= 1) {
+        f2 t[MAXG];
+#pragma unroll
+        for (int i = 0; i < len; i++) {
+            t[2 * i] = (v[i] + v[len + i]) * HAAR_C;
+            t[2 * i + 1] = (v[i] - v[len + i]) * HAAR_C;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * len; i++) v[i] = t[i];
+    }
+}
+
+// Hard threshold.  Spectrum layout: S[jp][2k + c] = coefficient plane j = 2 jp + c of block k,
+// so that the Haar transforms of two coefficient planes run as one packed instruction stream.
+template <int K>
+__device__ __forceinline__ void shrink_ht(f32v (&S)[4], float thr, int& nnz) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) {
+        f2 x[MAXG];
+#pragma unroll
+        for (int k = 0; k < K; k++) x[k] = mk2(S[jp][2 * k], S[jp][2 * k + 1]);
+        haar_fwd2<K>(x);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool k0 = fabsf(x[k].x) >= thr, k1 = fabsf(x[k].y) >= thr;
+            nnz += (k0 ? 1 : 0) + (k1 ? 1 : 0);
+            x[k] = mk2(k0 ? x[k].x : 0.0f, k1 ? x[k].y : 0.0f);
+        }
+        haar_inv2<K>(x);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            S[jp][2 * k] = x[k].x;
+            S[jp][2 * k + 1] = x[k].y;
+        }
+    }
+}
+// Empirical Wiener.  W = e / (e + sigma^2) is evaluated as e * rcp(e + sigma^2) (v_rcp_f32:
+// within 2 ulp of the correctly rounded quotient the oracle uses; the stage result is compared
+// with an fp32 tolerance anyway because the aggregation order differs).  (An interleaved
+// <32 x float> layout like the hard-threshold one needs 8 x 32 contiguous registers and spills.)
 template <int K>
 __device__ __forceinline__ void shrink_wiener(f16v (&spec)[8], f16v (&bspec)[8], float sigma2,
                                               float& sw) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        f16v s = spec[j], b = bspec[j];
-        haar_fwd<K>(s);
-        haar_fwd<K>(b);
+        f2 x[MAXG];
+#pragma unroll
+        for (int k = 0; k < K; k++) x[k] = mk2(spec[j][k], bspec[j][k]);
+        haar_fwd2<K>(x);
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const float e = b[k] * b[k];
-            const float W = e / (e + sigma2);
-            s[k] = W * s[k];
+            const float e = x[k].y * x[k].y;
+            const float W = e * __builtin_amdgcn_rcpf(e + sigma2);
             sw += W * W;
+            x[k] = mk2(W * x[k].x, 0.0f);
         }
+        f16v s;
+#pragma unroll
+        for (int k = 0; k < K; k++) s[k] = x[k].x;
         haar_inv<K>(s);
         spec[j] = s;
     }
 }
 
-// Workgroup-wide spin lock in LDS (one lane of the wave takes it for the whole wave).
 // The CU's LDS serves the instructions of all its waves in arrival order, so the ring accesses
 // of the lock holder are ordered against the next holder's by the lock word itself: only the
 // compiler has to be kept from moving ring accesses across lock / unlock (no s_waitcnt, which
@@ -325,12 +373,19 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
     int K = 1;
     while (K * 2 <= count) K *= 2;
 
-    f16v spec[8];
-    f16v bspec[8];
+    // Spectrum registers (layouts: see shrink_ht / shrink_wiener).
+    f32v S[4];                       // hard threshold: interleaved coefficient planes
+    f16v spec[WIENER ? 8 : 1];       // Wiener: noisy spectrum [plane][block]
+    f16v bspec[WIENER ? 8 : 1];      // Wiener: basic-estimate spectrum
+    if constexpr (WIENER) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        spec[j] = (f16v)(0.0f);
-        bspec[j] = (f16v)(0.0f);
+        for (int j = 0; j < 8; j++) {
+            spec[j] = (f16v)(0.0f);
+            bspec[j] = (f16v)(0.0f);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) S[j] = (f32v)(0.0f);
     }
 
     // Forward transforms, two streams per iteration: (noisy k, basic k) for Wiener, blocks
@@ -366,7 +421,7 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
 #pragma unroll
         for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
         pair_fwd(T, tb, hi, lo, v2);
-        if (WIENER) {
+        if constexpr (WIENER) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 spec[j][k] = v2[j].x;
@@ -374,10 +429,10 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; j++) spec[j][k] = v2[j].x;
+            for (int j = 0; j < 8; j++) S[j >> 1][2 * k + (j & 1)] = v2[j].x;
             if (K > 1) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) spec[j][k + 1] = v2[j].y;
+                for (int j = 0; j < 8; j++) S[j >> 1][2 * k + 2 + (j & 1)] = v2[j].y;
             }
         }
 #pragma unroll
@@ -390,14 +445,14 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
     STAMP(t1);
     STAMP_ADD(0, t0, t1);
     float w;
-    if (!WIENER) {
+    if constexpr (!WIENER) {
         int nnz = 0;
         switch (K) {
-            case 16: shrink_ht<16>(spec, thr, nnz); break;
-            case 8: shrink_ht<8>(spec, thr, nnz); break;
-            case 4: shrink_ht<4>(spec, thr, nnz); break;
-            case 2: shrink_ht<2>(spec, thr, nnz); break;
-            default: shrink_ht<1>(spec, thr, nnz); break;
+            case 16: shrink_ht<16>(S, thr, nnz); break;
+            case 8: shrink_ht<8>(S, thr, nnz); break;
+            case 4: shrink_ht<4>(S, thr, nnz); break;
+            case 2: shrink_ht<2>(S, thr, nnz); break;
+            default: shrink_ht<1>(S, thr, nnz); break;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
@@ -422,26 +477,35 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
     STAMP(t2);
     STAMP_ADD(1, t1, t2);
 
+    // element (plane j, block k) of the filtered spectrum / of the spatial estimate
+    auto sget = [&](int j, int k) -> float {
+        if constexpr (WIENER)
+            return spec[j][k];
+        else
+            return S[j >> 1][2 * k + (j & 1)];
+    };
+    auto sput = [&](int j, int k, float v) {
+        if constexpr (WIENER)
+            spec[j][k] = v;
+        else
+            S[j >> 1][2 * k + (j & 1)] = v;
+    };
+
     // Inverse 3-D DCT of every block (two per iteration), results kept in the spectrum
     // registers (now layout L1: hi = z, lo = x, plane index = y).
     for (int k = 0; k < K; k += 2) {
         const int k2 = (k + 1 < K) ? k + 1 : k;
 #pragma unroll
-        for (int j = 0; j < 8; j++) v2[j] = mk2(spec[j][k], spec[j][k2]);
+        for (int j = 0; j < 8; j++) v2[j] = mk2(sget(j, k), sget(j, k2));
         pair_inv(T, tb, hi, lo, v2);
 #pragma unroll
-        for (int j = 0; j < 8; j++) spec[j][k] = v2[j].x;
+        for (int j = 0; j < 8; j++) sput(j, k, v2[j].x);
         if (k2 != k) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) spec[j][k2] = v2[j].y;
+            for (int j = 0; j < 8; j++) sput(j, k2, v2[j].y);
         }
     }
 
-    // Aggregate into the LDS ring.  LDS float atomics (ds_add_f32) run at about one lane per
-    // two cycles on gfx950 (measured: 76 LDS-array cycles per LDS instruction with them), so
-    // the adds are plain read-modify-writes under a workgroup lock instead.  LDS executes
-    // instructions in issue order, so within the lock holder overlapping blocks of one group
-    // are added correctly one after the other.
     STAMP(t3);
     STAMP_ADD(2, t2, t3);
     // lock[0] = ring lock, lock[1] = groups aggregated so far, lock[2] = layers whose entry
@@ -465,7 +529,7 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
         for (int y = 0; y < 8; y++) acc[y] = ring[off + y * REG];
 #pragma unroll
         for (int y = 0; y < 8; y++)
-            ring[off + y * REG] = acc[y] + mk2(ww[y] * spec[y][k], ww[y]);
+            ring[off + y * REG] = acc[y] + mk2(ww[y] * sget(y, k), ww[y]);
     }
     ring_unlock(lock, lane);
     STAMP(t5);
