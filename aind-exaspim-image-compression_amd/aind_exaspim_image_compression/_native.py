@@ -109,6 +109,7 @@ SIGNATURES = {
     "exabm4d_tile_gather_dev": (_I, [_CTX, c_vp, _I, _I, _I, c_i32p, _I, _I, c_vp]),
     "exabm4d_tile_accumulate_dev": (_I, [_CTX, c_vp, c_i32p, _I, _I, _I, c_vp, c_vp, _I, _I, _I]),
     "exabm4d_tile_finalize_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, c_vp, _SZ]),
+    "exabm4d_chunk_byte_histograms_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, c_vp]),
 }
 
 _lib = None
@@ -354,6 +355,12 @@ class Context:
     def tile_finalize(self, tf, acc, wgt, out, n):
         self._check(lib().exabm4d_tile_finalize_u16_dev(self.handle, ctypes.byref(tf), _ptr(acc),
                                                         _ptr(wgt), _ptr(out), n))
+
+    def chunk_byte_histograms(self, vol, shape, chunk, hist):
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_chunk_byte_histograms_dev(self.handle, _ptr(vol), nz, ny, nx,
+                                                            int(chunk[0]), int(chunk[1]),
+                                                            int(chunk[2]), _ptr(hist)))
 
     def close(self):
         if self.handle and os.getpid() == self.pid:

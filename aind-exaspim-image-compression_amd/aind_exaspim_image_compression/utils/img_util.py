@@ -1,0 +1,70 @@
+"""Compression-ratio operators (SURVEY.md section 8 "next" row f-1).
+
+``compute_cratio`` keeps the reference's signature and semantics (reference
+``utils/img_util.py:401-441``): C-order chunks of ``patch_shape``, ``codec.encode(chunk)``,
+ratio rounded to two decimals.  The codec is whatever object the caller passes -- the reference
+passes ``numcodecs.blosc.Blosc(cname="zstd", clevel=5|6, shuffle=SHUFFLE)`` (``evaluate.py:40``,
+``scripts/evaluate_bm4dnet.py:140``), which is third-party and not part of this repo.
+
+``shuffled_entropy_cratio`` is the MI355X-side rate proxy: a HIP kernel builds, per 64^3 chunk,
+the histograms of the two byte planes Blosc's SHUFFLE filter produces; the zeroth-order entropy
+of those planes bounds what an order-0 entropy coder behind the shuffle can reach.  It is a proxy
+for rate-distortion sweeps that keeps the volume in HBM, NOT the Blosc/zstd byte count (zstd also
+exploits repeats); parity of the histograms with numpy is exact and tested.
+"""
+import numpy as np
+
+from aind_exaspim_image_compression import _native
+
+
+def compute_cratio(img, codec, patch_shape=(64, 64, 64)):
+    """Chunked compression ratio = total raw bytes / total ``codec.encode`` bytes."""
+    img = np.asarray(img)
+    if img.ndim == 5:
+        img = img[0, 0]
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    raw = 0
+    packed = 0
+    grids = [range(0, s, c) for s, c in zip(img.shape, patch_shape)]
+    for z0 in grids[0]:
+        for y0 in grids[1]:
+            for x0 in (grids[2] if len(grids) > 2 else [0]):
+                chunk = np.ascontiguousarray(img[z0:z0 + patch_shape[0], y0:y0 + patch_shape[1],
+                                                 x0:x0 + patch_shape[2]])
+                packed += len(codec.encode(chunk))
+                raw += chunk.nbytes
+    return round(raw / packed, 2)
+
+
+def chunk_byte_histograms(img, patch_shape=(64, 64, 64), device=None):
+    """[nchunks, 2, 256] uint32 histograms of the low / high byte planes of every chunk (GPU)."""
+    vol = np.ascontiguousarray(img, dtype=np.uint16)
+    if vol.ndim != 3:
+        raise ValueError("expected a 3-D uint16 volume")
+    ctx = _native.context(device)
+    n = int(np.prod([-(-s // c) for s, c in zip(vol.shape, patch_shape)]))
+    d_vol = ctx.to_device(vol)
+    d_hist = ctx.alloc(n * 512 * 4)
+    try:
+        ctx.chunk_byte_histograms(d_vol, vol.shape, patch_shape, d_hist)
+        ctx.sync()
+        return d_hist.download((n, 2, 256), np.uint32)
+    finally:
+        d_vol.free()
+        d_hist.free()
+
+
+def entropy_bytes(hist):
+    """Zeroth-order entropy bound in bytes of the byte planes described by ``hist[..., 256]``."""
+    h = np.asarray(hist, dtype=np.float64)
+    n = h.sum(axis=-1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bits = -np.where(h > 0, h * np.log2(h / n), 0.0).sum(axis=-1)
+    return bits / 8.0
+
+
+def shuffled_entropy_cratio(img, patch_shape=(64, 64, 64), device=None):
+    """Raw bytes / order-0 entropy bound of the byte-shuffled chunks, rounded like compute_cratio."""
+    hist = chunk_byte_histograms(img, patch_shape, device)
+    raw = float(hist[:, 0, :].sum()) * 2.0
+    return round(raw / max(float(entropy_bytes(hist).sum()), 1.0), 2)

@@ -171,6 +171,38 @@ __global__ __launch_bounds__(EW_THREADS) void tile_finalize_kernel(TfDev t,
     }
 }
 
+// ---- chunked byte-plane histograms (row f-1) -----------------------------------------------------
+// One workgroup per chunk; LDS integer atomics (full rate, unlike ds_add_f32) on 2 x 256 bins.
+__global__ __launch_bounds__(EW_THREADS) void chunk_hist_kernel(const uint16_t* __restrict__ vol,
+                                                                int nz, int ny, int nx, int cz,
+                                                                int cy, int cx, int gcy, int gcx,
+                                                                uint32_t* __restrict__ hist) {
+    __shared__ unsigned int h[512];
+    for (int i = threadIdx.x; i < 512; i += EW_THREADS) h[i] = 0u;
+    __syncthreads();
+    const int c = blockIdx.x;
+    const int bx = c % gcx, by = (c / gcx) % gcy, bz = c / (gcx * gcy);
+    const int z0 = bz * cz, y0 = by * cy, x0 = bx * cx;
+    const int ez = min(cz, nz - z0), ey = min(cy, ny - y0), ex = min(cx, nx - x0);
+    const size_t total = (size_t)ez * ey * ex;
+    for (size_t i = threadIdx.x; i < total; i += EW_THREADS) {
+        const int x = (int)(i % ex), y = (int)((i / ex) % ey), z = (int)(i / ((size_t)ex * ey));
+        const unsigned v = vol[((size_t)(z0 + z) * ny + (y0 + y)) * nx + (x0 + x)];
+        atomicAdd(&h[v & 255u], 1u);
+        atomicAdd(&h[256u + (v >> 8)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += EW_THREADS) hist[(size_t)c * 512 + i] = h[i];
+}
+
+hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz, int cy, int cx,
+                             uint32_t* hist, hipStream_t s) {
+    const int gz = (nz + cz - 1) / cz, gy = (ny + cy - 1) / cy, gx = (nx + cx - 1) / cx;
+    hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)(gz * gy * gx)), dim3(EW_THREADS), 0, s,
+                       vol, nz, ny, nx, cz, cy, cx, gy, gx, hist);
+    return hipGetLastError();
+}
+
 static inline unsigned ew_blocks(size_t n) {
     size_t b = (n + EW_THREADS - 1) / EW_THREADS;
     if (b > (size_t)EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;

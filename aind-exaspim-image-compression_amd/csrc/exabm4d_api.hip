@@ -645,4 +645,15 @@ int exabm4d_tile_finalize_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
     return EXABM4D_OK;
 }
 
+// ---- encode front end (row f-1) ---------------------------------------------------------------------
+int exabm4d_chunk_byte_histograms_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx,
+                                      int cz, int cy, int cx, uint32_t* hist) {
+    if (!ctx || !vol || !hist) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (nz < 1 || ny < 1 || nx < 1 || cz < 1 || cy < 1 || cx < 1)
+        return fail(ctx, EXABM4D_ERR_INVALID, "bad sizes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_chunk_hist(vol, nz, ny, nx, cz, cy, cx, hist, ctx->stream));
+    return EXABM4D_OK;
+}
+
 }  // extern "C"

@@ -34,6 +34,8 @@ hipError_t launch_tile_accumulate(const float* preds, const int* starts, int nb,
                                   float* acc, float* wgt, int nz, int ny, int nx, hipStream_t s);
 hipError_t launch_tile_finalize(const TfDev& t, const float* acc, const float* wgt, uint16_t* out,
                                 size_t n, hipStream_t s);
+hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz, int cy, int cx,
+                             uint32_t* hist, hipStream_t s);
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic);
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,

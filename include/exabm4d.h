@@ -211,6 +211,18 @@ int exabm4d_tile_finalize_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
                                   const float* accum_pred, const float* accum_wgt, uint16_t* out,
                                   size_t n);
 
+/* ---- encode half of the metric (SURVEY.md section 8 "next" row f-1) ---------------------------- */
+/* Per-chunk byte-plane histograms of a uint16 volume: the front end of the reference's
+ * chunked compression ratio, compute_cratio(img, Blosc(zstd, SHUFFLE), patch_shape=(64,64,64))
+ * (utils/img_util.py:401-441; codec evaluate.py:40).  Blosc's SHUFFLE filter regroups a chunk's
+ * bytes into a low-byte plane and a high-byte plane before the entropy coder; hist receives
+ * [nchunks][2][256] uint32 counts (plane 0 = low bytes), chunks in (z,y,x) raster order of
+ * ceil(n/c) chunks per axis, edge chunks truncated like numpy slicing.  From these the host
+ * derives a zeroth-order entropy bound of the shuffled stream (a rate proxy; the exact Blosc/zstd
+ * byte counts need the third-party codec). */
+int exabm4d_chunk_byte_histograms_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx,
+                                      int cz, int cy, int cx, uint32_t* hist);
+
 #ifdef __cplusplus
 }
 #endif

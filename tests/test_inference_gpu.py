@@ -106,3 +106,30 @@ def test_predict_with_unet_and_predict_patch():
     a = out[5:57, 5:59, 5:59].astype(np.int32)
     b = p[5:57, 5:59, 5:59].astype(np.int32)
     assert np.mean(np.abs(a - b) > 1) < 1e-3
+
+
+def test_chunk_byte_histograms_and_cratio(ctx):
+    """Row f-1 front end: per-chunk byte-plane histograms (integer-exact vs numpy), the entropy
+    rate proxy, and compute_cratio's chunk walk with a stand-in codec."""
+    from aind_exaspim_image_compression.utils import img_util
+    rng = np.random.default_rng(4)
+    vol = (37 + rng.normal(0, 24, (70, 64, 100))).clip(0, 65535).round().astype(np.uint16)
+    vol[10:20, 5:9, 50:60] += 3000
+    got = img_util.chunk_byte_histograms(vol, (64, 64, 64))
+    want = []
+    for z0 in range(0, 70, 64):
+        for y0 in range(0, 64, 64):
+            for x0 in range(0, 100, 64):
+                c = vol[z0:z0 + 64, y0:y0 + 64, x0:x0 + 64].reshape(-1)
+                want.append([np.bincount(c & 255, minlength=256), np.bincount(c >> 8, minlength=256)])
+    np.testing.assert_array_equal(got, np.array(want, dtype=np.uint32))
+    assert got.sum() == 2 * vol.size
+
+    class Half:                                   # stand-in codec: "compresses" to half the bytes
+        def encode(self, chunk):
+            return bytes(chunk.nbytes // 2)
+    assert img_util.compute_cratio(vol, Half()) == 2.0
+    assert img_util.compute_cratio(vol[None, None], Half()) == 2.0
+    smooth = np.full((64, 64, 64), 1000, np.uint16)
+    assert img_util.shuffled_entropy_cratio(vol) < img_util.shuffled_entropy_cratio(smooth)
+    assert 1.5 < img_util.shuffled_entropy_cratio(vol) < 4.0
