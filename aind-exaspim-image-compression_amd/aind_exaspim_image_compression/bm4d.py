@@ -36,6 +36,22 @@ class BM4DProfile:
         return _native.default_params(**asdict(self))
 
 
+_MAX_VOXELS_PER_CALL = 1 << 30     # ~21 GB of device scratch for the two-stage pipeline
+
+
+def _denoise_batched(ctx, arr, sigma, params, stages, clip):
+    """One device call per sub-batch of volumes (the reference's cache build runs 30 000
+    patches, scripts/precompute.py:278-319; they do not have to fit the GPU at once)."""
+    if arr.ndim == 3 or arr.shape[0] * arr[0].size <= _MAX_VOXELS_PER_CALL:
+        return ctx.denoise_f32_host(arr, sigma, params=params, stages=stages, clip=clip)
+    per = max(1, _MAX_VOXELS_PER_CALL // arr[0].size)
+    out = np.empty(arr.shape, dtype=np.float32)
+    for i in range(0, arr.shape[0], per):
+        out[i:i + per] = ctx.denoise_f32_host(arr[i:i + per], sigma, params=params,
+                                              stages=stages, clip=clip)
+    return out
+
+
 def _stages(stage_arg):
     if stage_arg in (None, "all", "ALL_STAGES", 2):
         return 2
@@ -57,8 +73,8 @@ def bm4d(z, sigma_psd, profile=None, stage_arg=None, device=None):
     sigma = float(np.asarray(sigma_psd).reshape(-1)[0])
     prof = profile or BM4DProfile()
     ctx = _native.context(device)
-    return ctx.denoise_f32_host(arr.astype(np.float32, copy=False), sigma, params=prof.native(),
-                                stages=_stages(stage_arg))
+    return _denoise_batched(ctx, arr.astype(np.float32, copy=False), sigma, prof.native(),
+                            _stages(stage_arg), None)
 
 
 def denoise_patches(raw, sigma, max_count=65535.0, profile=None, device=None):
@@ -70,8 +86,7 @@ def denoise_patches(raw, sigma, max_count=65535.0, profile=None, device=None):
         raw = raw[None]
     prof = profile or BM4DProfile()
     ctx = _native.context(device)
-    return ctx.denoise_f32_host(raw, float(sigma), params=prof.native(), stages=2,
-                                clip=(0.0, float(max_count)))
+    return _denoise_batched(ctx, raw, float(sigma), prof.native(), 2, (0.0, float(max_count)))
 
 
 def denoise_volume(vol_u16, sigma, offset=0.0, profile=None, stages=2, device=None):

@@ -27,6 +27,15 @@ def test_bm4d_shim_call_signature(oracle):
     t2 = denoise_patches(batch, SIGMA)
     assert t2.shape == batch.shape and t2.min() >= 0.0
     assert psnr(t2[0], teacher, 1000.0) > 80.0
+    # sub-batching (one device call per patch here) gives the same teachers
+    import aind_exaspim_image_compression.bm4d as B
+    old = B._MAX_VOXELS_PER_CALL
+    B._MAX_VOXELS_PER_CALL = 64 ** 3
+    try:
+        t3 = denoise_patches(batch, SIGMA)
+    finally:
+        B._MAX_VOXELS_PER_CALL = old
+    assert psnr(t3, t2, 1000.0) > 80.0
 
 
 def test_slab_driver_single_gpu(oracle):

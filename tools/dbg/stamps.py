@@ -14,7 +14,7 @@ ctx.denoise_u16(d_in, d_out, shape, 24.0, 37.0); ctx.sync()
 L.exabm4d_debug_stamps(out, 1)
 ctx.denoise_u16(d_in, d_out, shape, 24.0, 37.0); ctx.sync()
 L.exabm4d_debug_stamps(out, 1)
-names = ["fwd","shrink","inv","lockwait","scatter","gatherwait","flush+barrier","total"]
+names = ["fwd","shrink","inv","wait+lock","scatter","closer_flush","final_barrier","total"]
 for base,lab in ((0,"HT"),(8,"WIE")):
     tot = out[base+7]
     print(lab, {n: round(out[base+i]/tot,3) for i,n in enumerate(names)}, "total wave-cycles(100MHz ticks?)", tot)
