@@ -515,7 +515,6 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
             __builtin_amdgcn_s_sleep(4);
     }
     ring_lock(lock, lane);
-    __builtin_amdgcn_s_setprio(3);   // the lock holder is on everybody's critical path
     STAMP(t4);
     STAMP_ADD(3, t3, t4);
     for (int k = 0; k < K; k++) {
@@ -533,7 +532,6 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
             ring[off + y * REG] = acc[y] + mk2(ww[y] * sget(y, k), ww[y]);
     }
     ring_unlock(lock, lane);
-    __builtin_amdgcn_s_setprio(0);
     STAMP(t5);
     STAMP_ADD(4, t4, t5);
     // The wave that aggregates the layer's last group closes the layer (it flushes the planes
