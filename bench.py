@@ -48,34 +48,50 @@ ALGO_BYTES_PER_VOXEL = {
 }
 
 
-def synth_u16(shape, seed):
-    """Pedestal 37 + blurred bright random-walk 'neurites' (a 128^3 brick, mirror-tiled) +
-    N(0, 24) noise, rint, clip, uint16.  Deterministic in `seed`."""
-    from scipy.ndimage import gaussian_filter
-    rng = np.random.default_rng(seed)
-    b = 128
-    brick = np.zeros((b, b, b), dtype=np.float32)
-    for _ in range(48):
-        p = rng.uniform(0, b, 3)
-        amp = float(np.exp(rng.uniform(np.log(100.0), np.log(8000.0))))
-        for _ in range(int(rng.integers(200, 800))):
-            p = np.clip(p + rng.normal(0, 0.7, 3), 0, b - 1)
-            brick[int(p[0]), int(p[1]), int(p[2])] += amp
-    brick = gaussian_filter(brick, 1.5) * 12.0
-    nz, ny, nx = shape
+_BRICK = {}
 
-    def tile_axis(n):
-        idx = np.arange(n) % (2 * b)
+
+def _brick(seed):
+    """128^3 structure brick: blurred bright random-walk 'neurites' (counts above pedestal)."""
+    if seed not in _BRICK:
+        from scipy.ndimage import gaussian_filter
+        rng = np.random.default_rng([seed, 0xB41C])
+        b = 128
+        brick = np.zeros((b, b, b), dtype=np.float32)
+        for _ in range(48):
+            p = rng.uniform(0, b, 3)
+            amp = float(np.exp(rng.uniform(np.log(100.0), np.log(8000.0))))
+            for _ in range(int(rng.integers(200, 800))):
+                p = np.clip(p + rng.normal(0, 0.7, 3), 0, b - 1)
+                brick[int(p[0]), int(p[1]), int(p[2])] += amp
+        _BRICK[seed] = gaussian_filter(brick, 1.5) * 12.0
+    return _BRICK[seed]
+
+
+def synth_u16(shape, seed, z_range=None):
+    """Pedestal 37 + the mirror-tiled structure brick + N(0, 24) noise, rint, clip, uint16
+    (SURVEY.md section 8d).  Deterministic and random-access in z: the noise of every 32-plane
+    slab has its own seed, so a rank can regenerate exactly the planes [z0, z1) it holds."""
+    brick = _brick(seed)
+    b = brick.shape[0]
+    nz, ny, nx = shape
+    z0, z1 = (0, nz) if z_range is None else z_range
+
+    def tile_axis(idx):
+        idx = np.asarray(idx) % (2 * b)
         return np.where(idx < b, idx, 2 * b - 1 - idx)
 
-    iz, iy, ix = tile_axis(nz), tile_axis(ny), tile_axis(nx)
-    out = np.empty(shape, dtype=np.uint16)
+    iy, ix = tile_axis(np.arange(ny)), tile_axis(np.arange(nx))
+    out = np.empty((z1 - z0, ny, nx), dtype=np.uint16)
     slab = 32
-    for z0 in range(0, nz, slab):
-        z1 = min(nz, z0 + slab)
-        clean = brick[iz[z0:z1]][:, iy][:, :, ix] + np.float32(OFFSET)
-        noise = rng.standard_normal(clean.shape, dtype=np.float32) * np.float32(SIGMA)
-        out[z0:z1] = np.rint(np.clip(clean + noise, 0, 65535)).astype(np.uint16)
+    for s0 in range((z0 // slab) * slab, z1, slab):
+        rng = np.random.default_rng([seed, s0 // slab])
+        zs = np.arange(s0, min(s0 + slab, nz))
+        clean = brick[tile_axis(zs)][:, iy][:, :, ix] + np.float32(OFFSET)
+        noise = rng.standard_normal((slab, ny, nx), dtype=np.float32)[:len(zs)] * np.float32(SIGMA)
+        vals = np.rint(np.clip(clean + noise, 0, 65535)).astype(np.uint16)
+        a, e = max(z0, s0), min(z1, s0 + len(zs))
+        out[a - z0:e - z0] = vals[a - s0:e - s0]
     return out
 
 
@@ -111,6 +127,66 @@ def cpu_baseline(sample_edge, seed):
     }
 
 
+def run_slabs(args, rank, local_rank, world, dist):
+    """N ranks, ONE volume of N*size planes: every rank holds its z-slab plus a 24-plane halo,
+    runs stage 1, exchanges the basic estimate's halo with its slab neighbours (RCCL isend /
+    irecv), runs stage 2 and quantises its own planes.  Weak scaling (size^3 voxels per rank)."""
+    import torch
+    from aind_exaspim_image_compression.distributed import (SlabDenoiser, exchange_basic_halo,
+                                                            plan_slabs)
+    n = args.size
+    shape = (n * world, n, n)
+    plan = plan_slabs(shape[0], world, rank)
+    dev = torch.device("cuda", local_rank)
+    host = synth_u16(shape, seed=2000, z_range=(plan.p0, plan.p1))
+    raw = torch.from_numpy(host.view(np.int16)).to(dev)
+    den = SlabDenoiser(host.shape, SIGMA, dev)
+
+    def step():
+        counts = (raw.to(torch.int32) & 0xFFFF).to(torch.float32) - OFFSET
+        basic = den.stage1(counts)
+        exchange_basic_halo(basic, plan, dist=dist)
+        est = den.stage2(counts, basic)[plan.core]
+        return torch.clamp(est + OFFSET, 0.0, 65535.0).round().to(torch.int32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "denoised+encoded voxels/s on 1024^3 uint16",
+            "value": world * n ** 3 * args.steps / elapsed,
+            "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{shape[0]}x{n}x{n} uint16 volume in {world} z-slab(s), "
+                                   "two-stage BM4D, 24-plane halo exchange of the basic estimate",
+                       "volume": list(shape), "stages": 2,
+                       "sharding": "z-slabs, RCCL point-to-point halo exchange"},
+            "residual_std": float((out[::8, ::8, ::8].float()
+                                   - (raw[plan.core][::8, ::8, ::8].to(torch.int32) & 0xFFFF)
+                                   .float()).std()),
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +194,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="cubic volume edge per GPU")
     ap.add_argument("--stages", type=int, default=2)
+    ap.add_argument("--mode", choices=["volumes", "slabs"], default="volumes",
+                    help="N>1 sharding: 'volumes' = one independent volume per rank, no "
+                         "data-path collective (default); 'slabs' = one (N*size) x size x size "
+                         "volume split into z-slabs with an RCCL halo exchange of the basic "
+                         "estimate between the two stages (distributed.py)")
     ap.add_argument("--cpu-sample", type=int, default=128,
                     help="edge of the CPU-baseline sample (0 disables the baseline)")
     args = ap.parse_args()
@@ -138,6 +219,9 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     from aind_exaspim_image_compression import _native
+
+    if args.mode == "slabs":
+        return run_slabs(args, rank, local_rank, world, dist)
 
     ctx = _native.context(local_rank)
     shape = (args.size,) * 3
