@@ -56,6 +56,143 @@ __device__ __forceinline__ uint16_t quantise_u16(float c, float maxc) {
 constexpr int EW_THREADS = 256;
 constexpr int EW_MAX_BLOCKS = 256 * 8;
 
+// ---- 8 voxels per lane: 16-byte uint16 accesses, 2 x 16-byte fp32 accesses ----------------------
+__device__ __forceinline__ void ld8(const uint16_t* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[2 * i] = (float)(w[i] & 0xFFFFu);
+        v[2 * i + 1] = (float)(w[i] >> 16);
+    }
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(uint16_t* p, const uint16_t (&q)[8]) {
+    uint4 r;
+    r.x = (unsigned)q[0] | ((unsigned)q[1] << 16);
+    r.y = (unsigned)q[2] | ((unsigned)q[3] << 16);
+    r.z = (unsigned)q[4] | ((unsigned)q[5] << 16);
+    r.w = (unsigned)q[6] | ((unsigned)q[7] << 16);
+    *reinterpret_cast<uint4*>(p) = r;
+}
+
+// A stream operator provides one(i) for a single voxel and eight(i) for voxels [i, i+8).
+template <class Op>
+__global__ __launch_bounds__(EW_THREADS) void stream8_kernel(Op op, size_t n8) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += stride)
+        op.eight(8 * g);
+}
+template <class Op>
+__global__ __launch_bounds__(EW_THREADS) void stream1_kernel(Op op, size_t begin, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = begin + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        op.one(i);
+}
+
+struct OpCountsFromU16 {
+    const uint16_t* in;
+    float* out;
+    float offset;
+    __device__ void one(size_t i) const { out[i] = (float)in[i] - offset; }
+    __device__ void eight(size_t i) const {
+        float v[8];
+        ld8(in + i, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = v[k] - offset;
+        st8(out + i, v);
+    }
+};
+struct OpNormalizeU16 {
+    const float* num;
+    const float* den;
+    uint16_t* out;
+    float offset;
+    __device__ void one(size_t i) const { out[i] = quantise_u16(num[i] / den[i] + offset, 65535.0f); }
+    __device__ void eight(size_t i) const {
+        float a[8], b[8];
+        uint16_t q[8];
+        ld8(num + i, a);
+        ld8(den + i, b);
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = quantise_u16(a[k] / b[k] + offset, 65535.0f);
+        st8(out + i, q);
+    }
+};
+template <typename TIn>
+struct OpTfForward {
+    TfDev t;
+    const TIn* in;
+    float* out;
+    __device__ void one(size_t i) const { out[i] = tf_forward(t, (float)in[i]); }
+    __device__ void eight(size_t i) const {
+        float v[8];
+        ld8(in + i, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = tf_forward(t, v[k]);
+        st8(out + i, v);
+    }
+};
+struct OpTfInverseU16 {
+    TfDev t;
+    const float* in;
+    uint16_t* out;
+    __device__ void one(size_t i) const { out[i] = quantise_u16(tf_inverse_float(t, in[i]), t.maxc); }
+    __device__ void eight(size_t i) const {
+        float v[8];
+        uint16_t q[8];
+        ld8(in + i, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = quantise_u16(tf_inverse_float(t, v[k]), t.maxc);
+        st8(out + i, q);
+    }
+};
+struct OpTileFinalize {
+    TfDev t;
+    const float* acc;
+    const float* wgt;
+    uint16_t* out;
+    __device__ uint16_t f(float a, float w) const {
+        const float y = a / (w + 1e-8f);     // accum_wgt += 1e-8 ; accum_pred /= accum_wgt
+        return quantise_u16(tf_inverse_float(t, y), t.maxc);
+    }
+    __device__ void one(size_t i) const { out[i] = f(acc[i], wgt[i]); }
+    __device__ void eight(size_t i) const {
+        float a[8], w[8];
+        uint16_t q[8];
+        ld8(acc + i, a);
+        ld8(wgt + i, w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = f(a[k], w[k]);
+        st8(out + i, q);
+    }
+};
+
+static inline unsigned ew_blocks(size_t n);
+static inline bool aligned16(const void* a, const void* b, const void* c = nullptr) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15u) == 0;
+}
+// Launch `op` over n voxels: 8 per lane where every pointer is 16-byte aligned, one per lane for
+// the tail (or for everything when a caller hands in an unaligned view).
+template <class Op>
+static hipError_t launch_stream(const Op& op, size_t n, bool vec_ok, hipStream_t s) {
+    const size_t n8 = vec_ok ? n / 8 : 0;
+    if (n8) hipLaunchKernelGGL(stream8_kernel<Op>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, s, op, n8);
+    if (8 * n8 < n)
+        hipLaunchKernelGGL(stream1_kernel<Op>, dim3(ew_blocks(n - 8 * n8)), dim3(EW_THREADS), 0, s, op,
+                           8 * n8, n);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(EW_THREADS) void normalize_kernel(const float* __restrict__ num,
                                                                const float* __restrict__ den,
                                                                float* __restrict__ out, size_t n,
@@ -68,45 +205,16 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void counts_from_u16_kernel(const uint16_t* __restrict__ in,
-                                                                     float* __restrict__ out,
-                                                                     size_t n, float offset) {
+
+
+
+__global__ __launch_bounds__(EW_THREADS) void tf_inverse_float_kernel(TfDev t,
+                                                                      const float* __restrict__ in,
+                                                                      float* __restrict__ out,
+                                                                      size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = (float)in[i] - offset;
-}
-
-// out = rint(clip(num/den + offset, 0, 65535)) as uint16
-__global__ __launch_bounds__(EW_THREADS) void normalize_u16_kernel(const float* __restrict__ num,
-                                                                   const float* __restrict__ den,
-                                                                   uint16_t* __restrict__ out,
-                                                                   size_t n, float offset) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float v = num[i] / den[i] + offset;
-        out[i] = quantise_u16(v, 65535.0f);
-    }
-}
-
-template <typename TIn>
-__global__ __launch_bounds__(EW_THREADS) void tf_forward_kernel(TfDev t, const TIn* __restrict__ in,
-                                                                float* __restrict__ out, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = tf_forward(t, (float)in[i]);
-}
-
-template <bool QUANT>
-__global__ __launch_bounds__(EW_THREADS) void tf_inverse_kernel(TfDev t, const float* __restrict__ in,
-                                                                void* __restrict__ out, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float c = tf_inverse_float(t, in[i]);
-        if (QUANT)
-            reinterpret_cast<uint16_t*>(out)[i] = quantise_u16(c, t.maxc);
-        else
-            reinterpret_cast<float*>(out)[i] = c;
-    }
+        out[i] = tf_inverse_float(t, in[i]);
 }
 
 // ---- overlap tiling ------------------------------------------------------------------------------
@@ -158,18 +266,6 @@ __global__ __launch_bounds__(EW_THREADS) void tile_accumulate_kernel(const float
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void tile_finalize_kernel(TfDev t,
-                                                                   const float* __restrict__ acc,
-                                                                   const float* __restrict__ wgt,
-                                                                   uint16_t* __restrict__ out,
-                                                                   size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float w = wgt[i] + 1e-8f;      // accum_wgt += 1e-8
-        const float y = acc[i] / w;          // accum_pred /= accum_wgt
-        out[i] = quantise_u16(tf_inverse_float(t, y), t.maxc);
-    }
-}
 
 // ---- chunked byte-plane histograms (row f-1) -----------------------------------------------------
 // One workgroup per chunk; LDS integer atomics (full rate, unlike ds_add_f32) on 2 x 256 bins.
@@ -218,36 +314,27 @@ hipError_t launch_normalize(const float* num, const float* den, float* out, size
 }
 hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, float offset,
                                   hipStream_t s) {
-    hipLaunchKernelGGL(counts_from_u16_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, in, out,
-                       n, offset);
-    return hipGetLastError();
+    return launch_stream(OpCountsFromU16{in, out, offset}, n, aligned16(in, out), s);
 }
 hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,
                                 float offset, hipStream_t s) {
-    hipLaunchKernelGGL(normalize_u16_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, num, den,
-                       out, n, offset);
-    return hipGetLastError();
+    return launch_stream(OpNormalizeU16{num, den, out, offset}, n, aligned16(num, den, out), s);
 }
 hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,
                                  hipStream_t s) {
-    hipLaunchKernelGGL(tf_forward_kernel<uint16_t>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t,
-                       in, out, n);
-    return hipGetLastError();
+    return launch_stream(OpTfForward<uint16_t>{t, in, out}, n, aligned16(in, out), s);
 }
 hipError_t launch_tf_forward_f32(const TfDev& t, const float* in, float* out, size_t n,
                                  hipStream_t s) {
-    hipLaunchKernelGGL(tf_forward_kernel<float>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t, in,
-                       out, n);
-    return hipGetLastError();
+    return launch_stream(OpTfForward<float>{t, in, out}, n, aligned16(in, out), s);
 }
 hipError_t launch_tf_inverse(const TfDev& t, const float* in, void* out, size_t n, int quant,
                              hipStream_t s) {
     if (quant)
-        hipLaunchKernelGGL(tf_inverse_kernel<true>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t,
-                           in, out, n);
-    else
-        hipLaunchKernelGGL(tf_inverse_kernel<false>, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t,
-                           in, out, n);
+        return launch_stream(OpTfInverseU16{t, in, reinterpret_cast<uint16_t*>(out)}, n,
+                             aligned16(in, out), s);
+    hipLaunchKernelGGL(tf_inverse_float_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t, in,
+                       reinterpret_cast<float*>(out), n);
     return hipGetLastError();
 }
 hipError_t launch_tile_gather(const float* vol, int nz, int ny, int nx, const int* starts, int nb,
@@ -281,9 +368,7 @@ hipError_t launch_tile_accumulate(const float* preds, const int* starts, int nb,
 }
 hipError_t launch_tile_finalize(const TfDev& t, const float* acc, const float* wgt, uint16_t* out,
                                 size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(tile_finalize_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, s, t, acc,
-                       wgt, out, n);
-    return hipGetLastError();
+    return launch_stream(OpTileFinalize{t, acc, wgt, out}, n, aligned16(acc, wgt, out), s);
 }
 
 }  // namespace exabm4d
