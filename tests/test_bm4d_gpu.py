@@ -151,3 +151,59 @@ def test_bad_arguments_raise(ctx):
     with pytest.raises(ValueError):
         ctx.denoise_f32_host(np.zeros((8, 8, 8), np.float32), SIGMA,
                              params=nat.default_params(block=4))           # unsupported profile
+
+
+def test_zero_padded_volume_and_small_groups(ctx, oracle):
+    """Edge cases of the domain: a volume that is mostly zero padding (every candidate of a block
+    ties at distance 0, aggregation sees all-zero groups), a bright block with few matches
+    (group sizes 1, 2, 4, 8 appear) -- match tables bit-exact, both stages within tolerance."""
+    rng = np.random.default_rng(23)
+    vol = np.zeros((40, 36, 44), dtype=np.float32)
+    vol[12:28, 10:26, 14:34] = rng.normal(300.0, SIGMA, (16, 16, 20)).astype(np.float32)
+    vol[20:23, 15:18, 20:23] += 20000.0
+    keys = _keys_gpu(ctx, vol, SIGMA, 3.0)
+    want = oracle.blockmatch(vol, SIGMA, 3.0)
+    np.testing.assert_array_equal(keys, want)
+    counts = (want != 0xFFFFFFFF).sum(-1)
+    assert counts.min() < 16 and counts.max() == 16
+    num_w, den_w = oracle.stage(vol, want, SIGMA)
+    num_g, den_g = _stage_gpu(ctx, vol, want, SIGMA)
+    np.testing.assert_allclose(den_g, den_w, rtol=2e-5)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    basic = oracle.normalize(num_w, den_w)
+    keys2 = oracle.blockmatch(basic, SIGMA, 0.6)
+    np.testing.assert_array_equal(_keys_gpu(ctx, basic, SIGMA, 0.6), keys2)
+    num_w, den_w = oracle.stage(vol, keys2, SIGMA, basic=basic)
+    num_g, den_g = _stage_gpu(ctx, vol, keys2, SIGMA, basic=basic)
+    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+
+
+def test_batch_of_unaligned_volumes_stage1_u16(ctx, oracle):
+    """batch > 1 with extents that are not 8 (mod 4) (clamped last grid point on every axis) and
+    the hard-threshold-only uint16 pipeline."""
+    shape = (22, 27, 33)
+    vols = np.stack([synth_volume(shape, seed=s, as_u16=True)[0] for s in (41, 42)])
+    d_in = ctx.to_device(vols)
+    d_out = ctx.alloc(vols.nbytes)
+    ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0, stages=1, batch=2)
+    ctx.sync()
+    got = d_out.download(vols.shape, np.uint16)
+    for i in range(2):
+        want = oracle.bm4d_u16(vols[i], SIGMA, 37.0, stages=1)
+        d = np.abs(got[i].astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and np.mean(d > 0) < 2e-3
+
+
+def test_other_sigma_and_profile(ctx, oracle):
+    """sigma in other units (normalised data) and a non-default profile (beta = 0, lambda, c)."""
+    from aind_exaspim_image_compression import _native as nat
+    vol, clean = synth_volume((32, 32, 40), seed=29)
+    small = (vol / np.float32(4000.0)).astype(np.float32)
+    got = ctx.denoise_f32_host(small, SIGMA / 4000.0)
+    want = oracle.bm4d(small, SIGMA / 4000.0)
+    assert psnr(got, want, float(small.max() - small.min())) > 80.0
+    p = nat.default_params(kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
+    got = ctx.denoise_f32_host(vol, SIGMA, params=p)
+    want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
+    assert psnr(got, want, 1000.0) > 80.0
