@@ -177,6 +177,31 @@ struct OpTileFinalize {
     }
 };
 
+// uint16 input has only 65536 distinct values: for the fp64-math-bound asinh transform the
+// forward pass becomes a table lookup.  The table is filled by the same device function, so the
+// results are bit-identical to direct evaluation.
+__global__ __launch_bounds__(EW_THREADS) void tf_lut_build_kernel(TfDev t, float* __restrict__ lut) {
+    const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < 65536u) lut[v] = tf_forward(t, (float)v);
+}
+struct OpLutForward {
+    const float* lut;
+    const uint16_t* in;
+    float* out;
+    __device__ void one(size_t i) const { out[i] = lut[in[i]]; }
+    __device__ void eight(size_t i) const {
+        const uint4 r = *reinterpret_cast<const uint4*>(in + i);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[2 * k] = lut[w[k] & 0xFFFFu];
+            v[2 * k + 1] = lut[w[k] >> 16];
+        }
+        st8(out + i, v);
+    }
+};
+
 static inline unsigned ew_blocks(size_t n);
 static inline bool aligned16(const void* a, const void* b, const void* c = nullptr) {
     return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15u) == 0;
@@ -323,6 +348,13 @@ hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* ou
 hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,
                                  hipStream_t s) {
     return launch_stream(OpTfForward<uint16_t>{t, in, out}, n, aligned16(in, out), s);
+}
+hipError_t launch_tf_forward_u16_lut(const TfDev& t, float* lut, const uint16_t* in, float* out,
+                                     size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(tf_lut_build_kernel, dim3(65536 / EW_THREADS), dim3(EW_THREADS), 0, s, t, lut);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_stream(OpLutForward{lut, in, out}, n, aligned16(in, out), s);
 }
 hipError_t launch_tf_forward_f32(const TfDev& t, const float* in, float* out, size_t n,
                                  hipStream_t s) {

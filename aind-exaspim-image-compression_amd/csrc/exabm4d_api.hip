@@ -20,6 +20,7 @@ struct exabm4d_ctx {
     float dct[64];
     float win[512];
     float* win_dev = nullptr;
+    float* tf_lut = nullptr;   // 65536-entry forward table for uint16 input (asinh)
     double win_beta = -1.0;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -201,6 +202,7 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->win_dev) (void)hipFree(ctx->win_dev);
+    if (ctx->tf_lut) (void)hipFree(ctx->tf_lut);
     for (int i = 0; i < 2 * EXABM4D_PHASE_COUNT; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -575,6 +577,12 @@ int exabm4d_transform_forward_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform*
     int rc = make_tfdev(ctx, t, d);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (d.kind == EXABM4D_TF_ASINH && n >= ((size_t)1 << 20)) {
+        // asinh is evaluated in fp64: large uint16 volumes go through a 65536-entry table
+        if (!ctx->tf_lut) HIP_TRY(ctx, hipMalloc((void**)&ctx->tf_lut, 65536 * sizeof(float)));
+        HIP_TRY(ctx, launch_tf_forward_u16_lut(d, ctx->tf_lut, in, out, n, ctx->stream));
+        return EXABM4D_OK;
+    }
     HIP_TRY(ctx, launch_tf_forward_u16(d, in, out, n, ctx->stream));
     return EXABM4D_OK;
 }

@@ -24,6 +24,8 @@ hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* ou
                                 float offset, hipStream_t s);
 hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,
                                  hipStream_t s);
+hipError_t launch_tf_forward_u16_lut(const TfDev& t, float* lut, const uint16_t* in, float* out,
+                                     size_t n, hipStream_t s);
 hipError_t launch_tf_forward_f32(const TfDev& t, const float* in, float* out, size_t n,
                                  hipStream_t s);
 hipError_t launch_tf_inverse(const TfDev& t, const float* in, void* out, size_t n, int quant,

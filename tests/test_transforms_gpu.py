@@ -106,3 +106,15 @@ def test_shapes_and_empty():
     assert t.inverse(t.forward(x)).dtype == np.uint16
     assert t.forward(np.zeros((0,), np.uint16)).shape == (0,)
     np.testing.assert_array_equal(t.inverse(t.forward(x)), x)
+
+
+def test_large_u16_volume_takes_the_table_path_bit_exact():
+    """>= 2^20 uint16 voxels with an asinh transform go through the 65536-entry device table
+    (filled by the same device function): identical bits to direct evaluation and to the oracle."""
+    cfg = TRANSFORM_CFGS["offset37_asinh_s32"]
+    t, o = T.build_transform(cfg), H.TransformOracle(cfg)
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 65536, size=(1 << 20) + 13).astype(np.uint16)
+    got = t.forward(big)
+    np.testing.assert_array_equal(got, o.forward(big))
+    np.testing.assert_array_equal(got[:4096], t.forward(big[:4096]))      # direct path
