@@ -477,35 +477,23 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
     STAMP(t2);
     STAMP_ADD(1, t1, t2);
 
-    // element (plane j, block k) of the filtered spectrum / of the spatial estimate
+    // element (plane j, block k) of the filtered spectrum
     auto sget = [&](int j, int k) -> float {
         if constexpr (WIENER)
             return spec[j][k];
         else
             return S[j >> 1][2 * k + (j & 1)];
     };
-    auto sput = [&](int j, int k, float v) {
-        if constexpr (WIENER)
-            spec[j][k] = v;
-        else
-            S[j >> 1][2 * k + (j & 1)] = v;
-    };
 
-    // Inverse 3-D DCT of every block (two per iteration), results kept in the spectrum
-    // registers (now layout L1: hi = z, lo = x, plane index = y).
-    for (int k = 0; k < K; k += 2) {
-        const int k2 = (k + 1 < K) ? k + 1 : k;
-#pragma unroll
-        for (int j = 0; j < 8; j++) v2[j] = mk2(sget(j, k), sget(j, k2));
-        pair_inv(T, tb, hi, lo, v2);
-#pragma unroll
-        for (int j = 0; j < 8; j++) sput(j, k, v2[j].x);
-        if (k2 != k) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) sput(j, k2, v2[j].y);
-        }
+    // Ring offsets of the blocks, decoded once: lane k < 16 holds block k's first ring plane
+    // slot and its (y,x) offset inside the region.
+    int my_slot0, my_yx;
+    {
+        int dz, dy, dx;
+        code_to_disp(mykey & KEY_CMASK, dz, dy, dx);
+        my_slot0 = (rz + dz + 5 + NPL) % NPL;
+        my_yx = (ry + dy - tg.y0) * REG + (rx + dx - tg.x0);
     }
-
     STAMP(t3);
     STAMP_ADD(2, t2, t3);
     // lock[0] = ring lock, lock[1] = groups aggregated so far, lock[2] = layers whose entry
@@ -514,26 +502,45 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
         while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
             __builtin_amdgcn_s_sleep(4);
     }
-    ring_lock(lock, lane);
-    STAMP(t4);
-    STAMP_ADD(3, t3, t4);
-    for (int k = 0; k < K; k++) {
-        const uint32_t key = __builtin_amdgcn_readlane(mykey, k);
-        int dz, dy, dx;
-        code_to_disp(key & KEY_CMASK, dz, dy, dx);
-        int slot = (rz + dz + 5) % NPL + hi;
-        slot -= slot >= NPL ? NPL : 0;
-        const int off = slot * PS + (ry + dy - tg.y0) * REG + (rx + dx - tg.x0) + lo;
-        f2 acc[8];
+
+    // Inverse 3-D DCT two blocks at a time and straight into the ring (layout L1: hi = z,
+    // lo = x, register index = y): the estimates never go back to the spectrum registers, and
+    // the lock is held only for the two read-modify-write bursts of a pair.
+    for (int k = 0; k < K; k += 2) {
+        const int k2 = (k + 1 < K) ? k + 1 : k;
 #pragma unroll
-        for (int y = 0; y < 8; y++) acc[y] = ring[off + y * REG];
+        for (int j = 0; j < 8; j++) v2[j] = mk2(sget(j, k), sget(j, k2));
+        pair_inv(T, tb, hi, lo, v2);
+        int slot_a = __builtin_amdgcn_readlane(my_slot0, k) + hi;
+        slot_a -= slot_a >= NPL ? NPL : 0;
+        const int off_a = slot_a * PS + __builtin_amdgcn_readlane(my_yx, k) + lo;
+        int slot_b = __builtin_amdgcn_readlane(my_slot0, k2) + hi;
+        slot_b -= slot_b >= NPL ? NPL : 0;
+        const int off_b = slot_b * PS + __builtin_amdgcn_readlane(my_yx, k2) + lo;
+        STAMP(tl0);
+        ring_lock(lock, lane);
+        STAMP(tl1);
+        STAMP_ADD(3, tl0, tl1);
+        {
+            f2 acc[8];
 #pragma unroll
-        for (int y = 0; y < 8; y++)
-            ring[off + y * REG] = acc[y] + mk2(ww[y] * sget(y, k), ww[y]);
+            for (int y = 0; y < 8; y++) acc[y] = ring[off_a + y * REG];
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+                ring[off_a + y * REG] = acc[y] + mk2(ww[y] * v2[y].x, ww[y]);
+        }
+        if (k2 != k) {
+            f2 acc[8];
+#pragma unroll
+            for (int y = 0; y < 8; y++) acc[y] = ring[off_b + y * REG];
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+                ring[off_b + y * REG] = acc[y] + mk2(ww[y] * v2[y].y, ww[y]);
+        }
+        ring_unlock(lock, lane);
+        STAMP(tl2);
+        STAMP_ADD(4, tl1, tl2);
     }
-    ring_unlock(lock, lane);
-    STAMP(t5);
-    STAMP_ADD(4, t4, t5);
     // The wave that aggregates the layer's last group closes the layer (it flushes the planes
     // the next layer retires); everybody else runs ahead into the next layer's transforms.
     int closer = 0;
