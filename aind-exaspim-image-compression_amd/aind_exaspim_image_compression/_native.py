@@ -77,6 +77,7 @@ SIGNATURES = {
     "exabm4d_create": (_I, [_I, ctypes.POINTER(_CTX)]),
     "exabm4d_destroy": (_I, [_CTX]),
     "exabm4d_set_stream": (_I, [_CTX, c_vp]),
+    "exabm4d_reset_stream": (_I, [_CTX]),
     "exabm4d_sync": (_I, [_CTX]),
     "exabm4d_default_params": (_I, [_PP]),
     "exabm4d_set_option": (_I, [_CTX, ctypes.c_char_p, _I]),
@@ -257,7 +258,13 @@ class Context:
         return {name: float(ms[i]) for i, name in enumerate(self.PHASES[:n])}
 
     def set_stream(self, hip_stream):
-        self._check(lib().exabm4d_set_stream(self.handle, hip_stream))
+        """Enqueue on an existing HIP stream handle; 0 / None is the HIP null stream (which is
+        what torch's default stream is)."""
+        self._check(lib().exabm4d_set_stream(self.handle, hip_stream or None))
+
+    def reset_stream(self):
+        """Back to the context's private non-blocking stream."""
+        self._check(lib().exabm4d_reset_stream(self.handle))
 
     # -- HIP events on the context's stream -------------------------------------------------
     def event(self):

@@ -138,7 +138,7 @@ class SlabDenoiser:
             out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
             ctx.normalize(self.num, self.den, out, n)
             stream.synchronize()
-            ctx.set_stream(None)
+            ctx.reset_stream()
         return out
 
     def stage1(self, noisy):

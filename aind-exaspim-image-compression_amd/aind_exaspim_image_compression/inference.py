@@ -92,7 +92,7 @@ def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, tri
         ctx.tile_finalize(transform.native_struct(), accum_pred, accum_wgt, result, n)
         stream.synchronize()
         out = result.cpu().numpy().view(np.uint16)
-        ctx.set_stream(None)
+        ctx.reset_stream()
     if pbar is not None:
         pbar.close()
     return out

@@ -212,15 +212,21 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
 
 int exabm4d_set_stream(exabm4d_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (hip_stream) {
-        ctx->stream = (hipStream_t)hip_stream;
-        ctx->own_stream = false;
-    } else {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    ctx->stream = (hipStream_t)hip_stream;   // NULL = the HIP null stream (PyTorch's default)
+    ctx->own_stream = false;
+    return EXABM4D_OK;
+}
+
+int exabm4d_reset_stream(exabm4d_ctx* ctx) {
+    if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) return EXABM4D_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
     return EXABM4D_OK;
 }
 

@@ -97,8 +97,11 @@ const char* exabm4d_last_error(const exabm4d_ctx* ctx);
 int exabm4d_device_count(void);
 int exabm4d_create(int device, exabm4d_ctx** out);
 int exabm4d_destroy(exabm4d_ctx* ctx);
-/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream. */
+/* Enqueue on an existing hipStream_t, e.g. torch.cuda.current_stream().cuda_stream.  The handle
+ * is used as given: NULL is the HIP null (legacy default) stream, which is what PyTorch's default
+ * stream is.  exabm4d_reset_stream returns to the context's private non-blocking stream. */
 int exabm4d_set_stream(exabm4d_ctx* ctx, void* hip_stream);
+int exabm4d_reset_stream(exabm4d_ctx* ctx);
 int exabm4d_sync(exabm4d_ctx* ctx);
 int exabm4d_default_params(exabm4d_params* p);
 /* Diagnostic switches. "force_generic_bm" = 1 routes every reference block through the
