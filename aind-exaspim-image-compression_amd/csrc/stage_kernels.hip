@@ -391,11 +391,19 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
     // Forward transforms, two streams per iteration: (noisy k, basic k) for Wiener, blocks
     // (k, k+1) for the hard-threshold stage.  The next iteration's gather is issued before the
     // current pair is transformed so that its latency hides behind the arithmetic.
+    // Block corners are decoded once: lane k < 16 holds block k's displacement and its linear
+    // voxel offset; inside the loops a corner costs two v_readlane.
+    int my_dz, my_dy, my_dx;
+    code_to_disp(mykey & KEY_CMASK, my_dz, my_dy, my_dx);
+    const unsigned long long my_corner =
+        lane < MAXG ? (unsigned long long)(rz + my_dz) * sz + (unsigned long long)(ry + my_dy) * sy +
+                          (unsigned long long)(rx + my_dx)
+                    : 0ull;
+    const unsigned my_corner_lo = (unsigned)my_corner, my_corner_hi = (unsigned)(my_corner >> 32);
     auto corner_of = [&](int k) -> size_t {
-        const uint32_t key = __builtin_amdgcn_readlane(mykey, k);
-        int dz, dy, dx;
-        code_to_disp(key & KEY_CMASK, dz, dy, dx);
-        return (size_t)(rz + dz) * sz + (size_t)(ry + dy) * sy + (size_t)(rx + dx);
+        const unsigned lo32 = __builtin_amdgcn_readlane(my_corner_lo, k);
+        const unsigned hi32 = __builtin_amdgcn_readlane(my_corner_hi, k);
+        return ((size_t)hi32 << 32) | lo32;
     };
     const int kstep = WIENER ? 1 : 2;
     float a[8], b[8], na[8] = {}, nb[8] = {};
@@ -487,13 +495,8 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
 
     // Ring offsets of the blocks, decoded once: lane k < 16 holds block k's first ring plane
     // slot and its (y,x) offset inside the region.
-    int my_slot0, my_yx;
-    {
-        int dz, dy, dx;
-        code_to_disp(mykey & KEY_CMASK, dz, dy, dx);
-        my_slot0 = (rz + dz + 5 + NPL) % NPL;
-        my_yx = (ry + dy - tg.y0) * REG + (rx + dx - tg.x0);
-    }
+    const int my_slot0 = (rz + my_dz + 5 + NPL) % NPL;
+    const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
     STAMP(t3);
     STAMP_ADD(2, t2, t3);
     // lock[0] = ring lock, lock[1] = groups aggregated so far, lock[2] = layers whose entry
