@@ -194,9 +194,11 @@ __device__ __forceinline__ void load8p(const f2* p, f2 (&v)[8]) {
 // Issue the gather of one block (corner `src`) in layout L1 (hi = z, lo = x, regs y).
 __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy, size_t sz, int hi,
                                         int lo, float (&v)[8]) {
-    const float* p = src + (size_t)hi * sz + lo;
+    // uniform row base (SGPR pair) + one 32-bit lane offset: global_load with saddr, no 64-bit
+    // VALU address arithmetic per row (make_geom guarantees 7 planes fit 32-bit byte offsets)
+    const unsigned loff = (unsigned)hi * (unsigned)sz + (unsigned)lo;
 #pragma unroll
-    for (int y = 0; y < 8; y++) v[y] = p[(size_t)y * sy];
+    for (int y = 0; y < 8; y++) v[y] = (src + (size_t)y * sy)[loff];
 }
 
 // 3-D DCT of TWO blocks at once (streams .x / .y; the transpose buffer holds float2 elements).
