@@ -77,6 +77,11 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     uint32_t list[MAXG];
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
+    // bit d set iff candidate displacement dx = d - 5 keeps the block inside the volume
+    uint32_t xmask = 0;
+#pragma unroll
+    for (int d = 0; d < SWIN; d++)
+        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
 
     auto step_plane = [&](int step, int& dylo) -> const float* {
         const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
@@ -199,13 +204,19 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             const float* lo_w = cur + lane;                                  // cells of wave cz
             const float* hi_w = pbuf_all[min(cz + 1, TC - 1)][step & 1] + lane;  // wave cz + 1
             // NE / 2 dy values per round (33 sums per cell fit the 36 slots of a plane buffer):
-            // two barrier pairs per pass instead of six.
+            // two barrier pairs per pass instead of six.  Each cell lane first adds its
+            // x-neighbour's sum (DPP row_shl:1, no LDS), so a reference lane reads 4 values per
+            // candidate instead of 8: S = ((c000+c001)+(c010+c011)) + ((c100+c101)+(c110+c111)).
 #pragma unroll
             for (int e0 = 0; e0 < NE; e0 += NE / 2) {
 #pragma unroll
                 for (int e = e0; e < e0 + NE / 2; e++)
 #pragma unroll
-                    for (int d = 0; d < SWIN; d++) mine[64 * ((e - e0) * SWIN + d)] = acc[e][d];
+                    for (int d = 0; d < SWIN; d++) {
+                        const float right = __int_as_float(__builtin_amdgcn_update_dpp(
+                            0, __float_as_int(acc[e][d]), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+                        mine[64 * ((e - e0) * SWIN + d)] = acc[e][d] + right;
+                    }
                 __syncthreads();
                 if (ref_ok) {
 #pragma unroll
@@ -213,18 +224,17 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                         const int dy = dylo + e;
                         if (dy <= RAD) {                   // dy = 6 of the second pass is a dummy
                             const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
+                            const uint32_t cbase =
+                                1u + (uint32_t)(((dz + RAD) * SWIN + (dy + RAD)) * SWIN);
+                            const bool self_row = (dz == 0) && (dy == 0);
 #pragma unroll
                             for (int d = 0; d < SWIN; d++) {
                                 const float* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
                                 const float* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
-                                const float lo = (c0[0] + c0[1]) + (c0[8] + c0[9]);
-                                const float hi = (c1[0] + c1[1]) + (c1[8] + c1[9]);
-                                const float S = lo + hi;
-                                const int dx = d - RAD;
-                                const bool valid =
-                                    vzy && (rx + dx >= 0) && (rx + dx <= g.nx - BLK);
-                                uint32_t key =
-                                    (__float_as_uint(S) & KEY_DMASK) | disp_code(dz, dy, dx);
+                                const float S = (c0[0] + c0[8]) + (c1[0] + c1[8]);
+                                const uint32_t code = (d == RAD && self_row) ? 0u : cbase + d;
+                                const bool valid = vzy && ((xmask >> d) & 1u);
+                                uint32_t key = (__float_as_uint(S) & KEY_DMASK) | code;
                                 key = (valid && key < keymax) ? key : KEY_EMPTY;
                                 if (__any(key < list[MAXG - 1])) list_insert(list, key);
                             }

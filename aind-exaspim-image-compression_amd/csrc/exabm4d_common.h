@@ -52,14 +52,16 @@ __host__ __device__ inline void code_to_disp(uint32_t code, int& dz, int& dy, in
 }
 
 // Sorted (ascending) insertion of `key` into a 16-entry register list, dropping the largest.
-// Keys are unique, so min/max alone keep the list sorted.
+// For a sorted list L the updated entry is L'[k] = median(L[k-1], key, L[k]) (L[-1] = 0): one
+// v_med3_u32 per entry, all reading the OLD neighbours, so the list is updated in place from
+// the top down.  (Keys are unique; a key >= L[15] leaves the list unchanged.)
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+    return max(min(a, b), min(max(a, b), c));   // hipcc folds this into v_med3_u32
+}
 __device__ __forceinline__ void list_insert(uint32_t (&list)[MAXG], uint32_t key) {
 #pragma unroll
-    for (int k = 0; k < MAXG; k++) {
-        uint32_t lo = min(list[k], key);
-        key = max(list[k], key);
-        list[k] = lo;
-    }
+    for (int k = MAXG - 1; k >= 1; k--) list[k] = med3_u32(list[k - 1], key, list[k]);
+    list[0] = min(list[0], key);
 }
 
 }  // namespace exabm4d
