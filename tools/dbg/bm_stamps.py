@@ -14,5 +14,5 @@ out = (ctypes.c_ulonglong*8)()
 for i in range(2):
     ctx.blockmatch(d, shape, 24.0, 3.0, k); ctx.sync()
     L.exabm4d_debug_bm_stamps(out)
-names=["wait_dma","wait_A","issue_dma","compute","exchange","total"]
+names=["wait_dma","wait_A","issue_dma","compute","exchange","total","first_barrier"]
 print({n: round(out[i]/out[5],3) for i,n in enumerate(names)}, out[5])
