@@ -111,6 +111,14 @@ SIGNATURES = {
     "exabm4d_tile_accumulate_dev": (_I, [_CTX, c_vp, c_i32p, _I, _I, _I, c_vp, c_vp, _I, _I, _I]),
     "exabm4d_tile_finalize_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, c_vp, _SZ]),
     "exabm4d_chunk_byte_histograms_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, c_vp]),
+    "exabm4d_u16_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
+    "exabm4d_key_histogram_dev": (_I, [_CTX, c_vp, _I, _SZ, _I, ctypes.c_double, _I,
+                                       ctypes.c_uint64, c_vp]),
+    "exabm4d_minmax_dev": (_I, [_CTX, c_vp, _I, _SZ, c_vp]),
+    "exabm4d_masked_error_stats_dev": (_I, [_CTX, c_vp, _I, c_vp, _I, c_vp, _SZ,
+                                            ctypes.c_double, c_vp]),
+    "exabm4d_ssim3d_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, ctypes.c_double,
+                                ctypes.c_double, c_vp]),
 }
 
 _lib = None
@@ -368,6 +376,45 @@ class Context:
         self._check(lib().exabm4d_chunk_byte_histograms_dev(self.handle, _ptr(vol), nz, ny, nx,
                                                             int(chunk[0]), int(chunk[1]),
                                                             int(chunk[2]), _ptr(hist)))
+
+    # -- background offset + quality metrics (row f-4); inputs on device, scalars to the host ----
+    DTYPES = {np.dtype(np.uint16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+    def u16_histogram(self, vol, n):
+        hist = np.empty(65536, dtype=np.uint64)
+        self._check(lib().exabm4d_u16_histogram_dev(self.handle, _ptr(vol), n,
+                                                    hist.ctypes.data_as(c_vp)))
+        return hist
+
+    def key_histogram(self, vol, dtype, n, digit, prefix=0, center=None):
+        hist = np.empty(65536, dtype=np.uint64)
+        self._check(lib().exabm4d_key_histogram_dev(
+            self.handle, _ptr(vol), self.DTYPES[np.dtype(dtype)], n, 0 if center is None else 1,
+            0.0 if center is None else float(center), int(digit), int(prefix),
+            hist.ctypes.data_as(c_vp)))
+        return hist
+
+    def minmax(self, vol, dtype, n):
+        out = np.empty(2, dtype=np.float64)
+        self._check(lib().exabm4d_minmax_dev(self.handle, _ptr(vol), self.DTYPES[np.dtype(dtype)], n,
+                                             out.ctypes.data_as(c_vp)))
+        return float(out[0]), float(out[1])
+
+    def masked_error_stats(self, pred, pred_dtype, ref, ref_dtype, mask, n, thr=float("inf")):
+        out = np.empty(7, dtype=np.float64)
+        self._check(lib().exabm4d_masked_error_stats_dev(
+            self.handle, _ptr(pred), self.DTYPES[np.dtype(pred_dtype)], _ptr(ref),
+            self.DTYPES[np.dtype(ref_dtype)], _ptr(mask) if mask is not None else None, n,
+            float(thr), out.ctypes.data_as(c_vp)))
+        return out
+
+    def ssim3d_sum(self, a, b, dtype, shape, window, c1, c2):
+        out = np.empty(1, dtype=np.float64)
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_ssim3d_dev(self.handle, _ptr(a), _ptr(b),
+                                             self.DTYPES[np.dtype(dtype)], nz, ny, nx, int(window),
+                                             float(c1), float(c2), out.ctypes.data_as(c_vp)))
+        return float(out[0])
 
     def close(self):
         if self.handle and os.getpid() == self.pid:

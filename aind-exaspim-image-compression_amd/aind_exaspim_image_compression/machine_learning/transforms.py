@@ -8,12 +8,14 @@ kernel runs, the result is copied back; there is no CPU fallback.  Code that alr
 buffers uses ``forward_device`` / ``inverse_device`` and never leaves HBM
 (``inference.predict`` does).
 
-Only construction-time scalars (e.g. the normalisation constant) and ``estimate_offset`` are
-computed on the host, exactly where the reference computes them on the host.
+Only construction-time scalars (e.g. the normalisation constant) are computed on the host,
+exactly where the reference computes them on the host; ``estimate_offset`` reduces its sample to
+a histogram on the GPU and finishes the percentile on the host.
 """
 import numpy as np
 
 from aind_exaspim_image_compression import _native
+from aind_exaspim_image_compression.utils import order_stats
 
 _F32 = np.float32
 _KIND_IDS = {"asinh": 0, "anscombe": 1, "linear": 2}
@@ -207,16 +209,74 @@ class OffsetTransform(_DeviceTransform):
 
 
 def estimate_offset(sample, percentile=1.0, ignore_zeros=True):
-    """Robust background / black-point estimate in counts (reference transforms.py:414-438).
+    """Robust background / black-point estimate in counts (reference transforms.py:414-438):
+    ``np.percentile`` of the float32 sample, zeros (non-positive values) excluded unless nothing
+    else is there.
 
-    Host-side statistic, as in the reference (SURVEY.md section 8 row f-4 lists an on-device
-    histogram version as a later step)."""
-    values = np.asarray(sample, dtype=_F32).reshape(-1)
-    if ignore_zeros:
-        positive = values[values > 0]
-        if positive.size:
-            values = positive
-    return float(np.percentile(values, percentile))
+    The sample is reduced on the GPU: a uint16 sample to its exact
+    65536-bin histogram, a float sample to the digit histograms of a radix selection over its float32 values; the
+    percentile is then formed on the host with numpy's own float32 scalar steps
+    (``utils/order_stats.py``), so the value is the reference's bit for bit."""
+    sample = np.asarray(sample)
+    if sample.size == 0:
+        raise ValueError("estimate_offset needs a non-empty sample")
+    ctx = _native.context()
+    if sample.dtype == np.uint16:
+        flat = np.ascontiguousarray(sample).reshape(-1)
+        buf = ctx.to_device(flat)
+        try:
+            return estimate_offset_device(ctx, buf, flat.size, percentile, ignore_zeros)
+        finally:
+            buf.free()
+    flat = np.ascontiguousarray(sample, dtype=_F32).reshape(-1)
+    buf = ctx.to_device(flat)
+    try:
+        stats = order_stats.DeviceOrderStats(ctx, buf, _F32, flat.size, dtype=_F32)
+        if ignore_zeros:
+            skip = stats.count_not_positive()
+            if skip < stats.n:
+                stats = order_stats.Shifted(stats, skip)
+        return float(order_stats.percentile(stats, percentile))
+    finally:
+        buf.free()
+
+
+def estimate_offset_device(ctx, d_u16, n, percentile=1.0, ignore_zeros=True):
+    """``estimate_offset`` of ``n`` uint16 voxels already resident in HBM (device pointer,
+    ``DeviceBuffer`` or torch tensor)."""
+    hist = ctx.u16_histogram(d_u16, int(n))
+    stats = order_stats.from_u16_hist(hist, ignore_zeros=ignore_zeros, dtype=_F32)
+    return float(order_stats.percentile(stats, percentile))
+
+
+def background_offset_statistics(sample, percentile=0.1):
+    """The per-brain record of ``scripts/estimate_background_offsets.py:31-67`` for a uint16
+    volume: offset over the non-zero voxels, offset over all voxels, median of the non-zero voxels
+    and the fraction of zero voxels, from one device histogram."""
+    flat = np.ascontiguousarray(sample, dtype=np.uint16).reshape(-1)
+    ctx = _native.context()
+    buf = ctx.to_device(flat)
+    try:
+        hist = ctx.u16_histogram(buf, flat.size)
+    finally:
+        buf.free()
+    n = int(hist.sum())
+    nonzero = n - int(hist[0])
+    every = order_stats.from_u16_hist(hist, dtype=np.uint16)
+    if nonzero:
+        counts = hist.copy()
+        counts[0] = 0
+        pos = order_stats.from_u16_hist(counts, dtype=np.uint16)
+        offset = float(order_stats.percentile(pos, percentile))
+        med = float(order_stats.median(pos))
+    else:
+        offset = med = float("nan")
+    return {
+        "offset": offset,
+        "offset_all_voxels": float(order_stats.percentile(every, percentile)),
+        "median": med,
+        "zero_fraction": 1.0 - nonzero / n,
+    }
 
 
 _BUILDERS = {

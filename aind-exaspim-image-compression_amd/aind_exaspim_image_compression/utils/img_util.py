@@ -68,3 +68,67 @@ def shuffled_entropy_cratio(img, patch_shape=(64, 64, 64), device=None):
     hist = chunk_byte_histograms(img, patch_shape, device)
     raw = float(hist[:, 0, :].sum()) * 2.0
     return round(raw / max(float(entropy_bytes(hist).sum()), 1.0), 2)
+
+
+# ---- quality metrics on device ----------------------------------------
+def _device_pair(img1, img2):
+    """Upload two images with one common element type: uint16 when both are, float64 otherwise
+    (the reference widens everything to float64: img_util.py:981-982)."""
+    a, b = np.asarray(img1), np.asarray(img2)
+    if a.shape != b.shape:
+        raise ValueError("Input images must have the same dimensions")
+    if not (a.dtype == np.uint16 and b.dtype == np.uint16):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+    ctx = _native.context()
+    return ctx, a, ctx.to_device(np.ascontiguousarray(a).reshape(-1)), \
+        ctx.to_device(np.ascontiguousarray(b).reshape(-1))
+
+
+def ssim3D(img1, img2, data_range=None, window_size=16):
+    """Structural similarity of two 3-D images with a cubic uniform window (reference
+    ``utils/img_util.py:953-1003``): local moments by ``scipy.ndimage.uniform_filter`` semantics
+    ("reflect" boundary), ``C1 = (0.01 L)^2``, ``C2 = (0.03 L)^2``, mean of
+    ``num / (max(den, 1e-8) + 1e-6)``.
+
+    The moments and the SSIM map are formed by one fp64 HIP kernel that marches running box sums
+    along z (``exabm4d_ssim3d_dev``); for uint16 input and the default power-of-two window the
+    local moments are exact, and the result differs from the reference only by the summation order
+    of the final mean (relative 1e-15)."""
+    ctx, a, d_a, d_b = _device_pair(img1, img2)
+    try:
+        if a.ndim != 3:
+            raise ValueError("ssim3D expects 3-D images")
+        n = int(a.size)
+        if data_range is None:
+            lo1, hi1 = ctx.minmax(d_a, a.dtype, n)
+            lo2, hi2 = ctx.minmax(d_b, a.dtype, n)
+            data_range = max(hi1 - lo1, hi2 - lo2)
+        c1 = (0.01 * data_range) ** 2
+        c2 = (0.03 * data_range) ** 2
+        total = ctx.ssim3d_sum(d_a, d_b, a.dtype, a.shape, window_size, c1, c2)
+        return np.float64(total) / n
+    finally:
+        d_a.free()
+        d_b.free()
+
+
+def _abs_error_stats(img1, img2):
+    ctx, a, d_a, d_b = _device_pair(img1, img2)
+    try:
+        n = int(a.size)
+        return ctx.masked_error_stats(d_a, a.dtype, d_b, a.dtype, None, n), n
+    finally:
+        d_a.free()
+        d_b.free()
+
+
+def compute_mae(img1, img2):
+    """Mean absolute error (reference ``utils/img_util.py`` compute_mae)."""
+    out, n = _abs_error_stats(img1, img2)
+    return float(out[1] / n)
+
+
+def compute_lmax(img1, img2):
+    """Maximum absolute error (reference ``utils/img_util.py`` compute_lmax)."""
+    out, _ = _abs_error_stats(img1, img2)
+    return float(out[6])

@@ -24,6 +24,8 @@ struct exabm4d_ctx {
     double win_beta = -1.0;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* red = nullptr;       // metric entry points: histogram / partials / results
+    size_t red_bytes = 0;
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
     int profile = 0;           // exabm4d_set_option("profile")
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
@@ -122,6 +124,7 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return EXABM4D_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->red) (void)hipFree(ctx->red);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
     hipError_t e = hipMalloc(&ctx->scratch, bytes);
@@ -670,6 +673,88 @@ int exabm4d_chunk_byte_histograms_dev(exabm4d_ctx* ctx, const uint16_t* vol, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_chunk_hist(vol, nz, ny, nx, cz, cy, cx, hist, ctx->stream));
     return EXABM4D_OK;
+}
+
+// ---- background offset + quality metrics (row f-4) ---------------------------------------------------
+static int metric_scratch(exabm4d_ctx* ctx, size_t bytes) {
+    if (ctx->red_bytes >= bytes) return EXABM4D_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->red) (void)hipFree(ctx->red);
+    ctx->red = nullptr;
+    ctx->red_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->red, bytes));
+    ctx->red_bytes = bytes;
+    return EXABM4D_OK;
+}
+static int metric_fetch(exabm4d_ctx* ctx, void* host, const void* dev, size_t bytes) {
+    HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return EXABM4D_OK;
+}
+static bool bad_dtype(int d) { return d < EXABM4D_DT_U16 || d > EXABM4D_DT_F64; }
+
+int exabm4d_u16_histogram_dev(exabm4d_ctx* ctx, const uint16_t* vol, size_t n, uint64_t* hist_host) {
+    if (!ctx || !hist_host || (!vol && n)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = metric_scratch(ctx, 65536 * sizeof(uint64_t))) return rc;
+    HIP_TRY(ctx, launch_hist_u16(vol, n, (unsigned long long*)ctx->red, ctx->stream));
+    return metric_fetch(ctx, hist_host, ctx->red, 65536 * sizeof(uint64_t));
+}
+
+int exabm4d_key_histogram_dev(exabm4d_ctx* ctx, const void* vol, int dtype, size_t n, int absdev,
+                              double center, int digit, uint64_t prefix, uint64_t* hist_host) {
+    if (!ctx || !hist_host || (!vol && n)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (bad_dtype(dtype) || digit < 0 || digit > 3) return fail(ctx, EXABM4D_ERR_INVALID, "bad dtype / digit");
+    if (digit > 0 && digit < 4 && (prefix >> (16 * digit)) != 0)
+        return fail(ctx, EXABM4D_ERR_INVALID, "prefix wider than the digits above");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = metric_scratch(ctx, 65536 * sizeof(uint64_t))) return rc;
+    HIP_TRY(ctx, launch_hist_key(vol, dtype, n, absdev ? 1 : 0, center, digit,
+                                 (unsigned long long)prefix, (unsigned long long*)ctx->red,
+                                 ctx->stream));
+    return metric_fetch(ctx, hist_host, ctx->red, 65536 * sizeof(uint64_t));
+}
+
+int exabm4d_minmax_dev(exabm4d_ctx* ctx, const void* vol, int dtype, size_t n, double* out_host) {
+    if (!ctx || !vol || !out_host) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (bad_dtype(dtype) || n == 0) return fail(ctx, EXABM4D_ERR_INVALID, "bad dtype / empty input");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t np = (size_t)masked_stats_partials(n) * 2;
+    if (int rc = metric_scratch(ctx, (np + 2) * sizeof(double))) return rc;
+    double* d = (double*)ctx->red;
+    HIP_TRY(ctx, launch_minmax(vol, dtype, n, d + 2, d, ctx->stream));
+    return metric_fetch(ctx, out_host, d, 2 * sizeof(double));
+}
+
+int exabm4d_masked_error_stats_dev(exabm4d_ctx* ctx, const void* pred, int pred_dtype,
+                                   const void* ref, int ref_dtype, const uint8_t* mask, size_t n,
+                                   double thr, double* out_host) {
+    if (!ctx || !pred || !ref || !out_host) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (bad_dtype(pred_dtype) || bad_dtype(ref_dtype) || n == 0)
+        return fail(ctx, EXABM4D_ERR_INVALID, "bad dtype / empty input");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t np = (size_t)masked_stats_partials(n) * 7;
+    if (int rc = metric_scratch(ctx, (np + 8) * sizeof(double))) return rc;
+    double* d = (double*)ctx->red;
+    HIP_TRY(ctx, launch_masked_stats(pred, pred_dtype, ref, ref_dtype, mask, n, thr, d + 8, d,
+                                     ctx->stream));
+    return metric_fetch(ctx, out_host, d, 7 * sizeof(double));
+}
+
+int exabm4d_ssim3d_dev(exabm4d_ctx* ctx, const void* a, const void* b, int dtype, int nz, int ny,
+                       int nx, int window, double c1, double c2, double* sum_host) {
+    if (!ctx || !a || !b || !sum_host) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (bad_dtype(dtype) || nz < 1 || ny < 1 || nx < 1) return fail(ctx, EXABM4D_ERR_INVALID, "bad dtype / sizes");
+    if (window < 1 || window > ssim3d_max_window())
+        return fail(ctx, EXABM4D_ERR_UNSUPPORTED, "ssim window must be 1..32");
+    if ((long long)nz * ny * nx > (1ll << 40) || nz > (1 << 20) || ny > (1 << 20) || nx > (1 << 20))
+        return fail(ctx, EXABM4D_ERR_INVALID, "volume too large");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t np = (size_t)ssim3d_partials(nz, ny, nx);
+    if (int rc = metric_scratch(ctx, (np + 1) * sizeof(double))) return rc;
+    double* d = (double*)ctx->red;
+    HIP_TRY(ctx, launch_ssim3d(a, b, dtype, nz, ny, nx, window, c1, c2, d + 1, d, ctx->stream));
+    return metric_fetch(ctx, sum_host, d, sizeof(double));
 }
 
 }  // extern "C"

@@ -38,6 +38,19 @@ hipError_t launch_tile_finalize(const TfDev& t, const float* acc, const float* w
                                 size_t n, hipStream_t s);
 hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz, int cy, int cx,
                              uint32_t* hist, hipStream_t s);
+hipError_t launch_hist_u16(const uint16_t* vol, size_t n, unsigned long long* hist, hipStream_t s);
+hipError_t launch_hist_key(const void* vol, int dtype, size_t n, int absdev, double center, int digit,
+                           unsigned long long prefix, unsigned long long* hist, hipStream_t s);
+int masked_stats_partials(size_t n);
+hipError_t launch_masked_stats(const void* pred, int pred_dtype, const void* ref, int ref_dtype,
+                               const uint8_t* mask, size_t n, double thr, double* partials,
+                               double* out7, hipStream_t s);
+hipError_t launch_minmax(const void* a, int dtype, size_t n, double* partials, double* out2,
+                         hipStream_t s);
+int ssim3d_partials(int nz, int ny, int nx);
+int ssim3d_max_window();
+hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny, int nx, int w,
+                         double C1, double C2, double* partials, double* out1, hipStream_t s);
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic);
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,

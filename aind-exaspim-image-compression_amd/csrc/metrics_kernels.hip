@@ -2,7 +2,7 @@
 // metrics on volumes that already live in HBM (gfx950).
 //
 //   hist16_kernel        exact 65536-bin histogram of 16-bit keys (uint16 counts, or one 16-bit
-//                        digit of an order-preserving fp32 key): every percentile / median / MAD the
+//                        digit of an order-preserving fp64 key): every percentile / median / MAD the
 //                        reference takes with np.percentile (machine_learning/transforms.py:414-438,
 //                        scripts/estimate_background_offsets.py:31-67, machine_learning/metrics.py:352-424)
 //                        follows from it on the host without touching the volume again.
@@ -35,26 +35,34 @@ struct KeyU16 {
     }
     __device__ uint32_t one(size_t i) const { return p[i]; }
 };
-// Order-preserving key of an fp32 value: ascending unsigned keys <=> ascending floats.
-__device__ __forceinline__ uint32_t f32_key(uint32_t b) {
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-struct KeyF32 {
-    const float* p;
-    int pass;        // 0: high digit of every element; 1: low digit of elements whose high digit == sel
-    uint32_t sel;
-    static constexpr int PER = 4;
-    __device__ uint32_t digit(uint32_t bits) const {
-        const uint32_t k = f32_key(bits);
-        if (pass == 0) return k >> 16;
-        return (k >> 16) == sel ? (k & 0xFFFFu) : 0xFFFFFFFFu;
+// Order-preserving 64-bit key of a value widened to fp64 (optionally of its absolute deviation
+// from a centre): ascending unsigned keys <=> ascending values.  A radix selection over its four
+// 16-bit digits gives exact order statistics of any element type: pass d counts digit d of the
+// elements whose higher digits equal `prefix`.
+template <class T>
+struct KeyF64 {
+    const T* p;
+    double center;
+    int absdev;
+    int d;
+    unsigned long long prefix;
+    static constexpr int PER = 8;
+    __device__ uint32_t digit(T x) const {
+        double v = (double)x;
+        if (absdev) v = fabs(v - center);
+        const long long b = __double_as_longlong(v);
+        const unsigned long long k = b < 0 ? ~(unsigned long long)b
+                                           : ((unsigned long long)b | 0x8000000000000000ull);
+        const int shift = 48 - 16 * d;
+        if (d > 0 && (k >> (shift + 16)) != prefix) return 0xFFFFFFFFu;
+        return (uint32_t)(k >> shift) & 0xFFFFu;
     }
     __device__ void load(size_t vec, uint32_t (&k)[8]) const {
-        const uint4 v = reinterpret_cast<const uint4*>(p)[vec];
-        k[0] = digit(v.x); k[1] = digit(v.y); k[2] = digit(v.z); k[3] = digit(v.w);
-        k[4] = k[5] = k[6] = k[7] = 0xFFFFFFFFu;
+        const T* q = p + vec * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) k[e] = digit(q[e]);
     }
-    __device__ uint32_t one(size_t i) const { return digit(__float_as_uint(p[i])); }
+    __device__ uint32_t one(size_t i) const { return digit(p[i]); }
 };
 
 template <class Key>
@@ -109,16 +117,9 @@ static hipError_t launch_hist(Key key, size_t n, bool aligned, unsigned long lon
     hipError_t e = hipMemsetAsync(hist, 0, 65536 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
     if (n == 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hist16_kernel<KeyU16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hist16_kernel<KeyF32>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hist16_kernel<Key>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (e != hipSuccess) return e;
     const size_t per_chunk = (size_t)HIST_T * HIST_V * Key::PER;
     size_t blocks = (n + per_chunk - 1) / per_chunk;
     if (blocks > 1024) blocks = 1024;   // 4 rounds of one workgroup per CU
@@ -130,9 +131,13 @@ static hipError_t launch_hist(Key key, size_t n, bool aligned, unsigned long lon
 hipError_t launch_hist_u16(const uint16_t* vol, size_t n, unsigned long long* hist, hipStream_t s) {
     return launch_hist(KeyU16{vol}, n, ((uintptr_t)vol & 15u) == 0, hist, s);
 }
-hipError_t launch_hist_f32(const float* vol, size_t n, int pass, uint32_t sel,
-                           unsigned long long* hist, hipStream_t s) {
-    return launch_hist(KeyF32{vol, pass, sel}, n, ((uintptr_t)vol & 15u) == 0, hist, s);
+hipError_t launch_hist_key(const void* vol, int dtype, size_t n, int absdev, double center, int digit,
+                           unsigned long long prefix, unsigned long long* hist, hipStream_t s) {
+    switch (dtype) {
+        case 0: return launch_hist(KeyF64<uint16_t>{(const uint16_t*)vol, center, absdev, digit, prefix}, n, true, hist, s);
+        case 1: return launch_hist(KeyF64<float>{(const float*)vol, center, absdev, digit, prefix}, n, true, hist, s);
+        default: return launch_hist(KeyF64<double>{(const double*)vol, center, absdev, digit, prefix}, n, true, hist, s);
+    }
 }
 
 // ---- fixed-order final reduction of per-workgroup partials ------------------------------------------
@@ -194,15 +199,16 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], unsigned max_
 
 // ---- masked absolute-error statistics --------------------------------------------------------------
 // columns: 0 sum|p-r| over foreground, 1 sum|p-r| over background, 2 foreground voxels,
-//          3 background voxels with p > thr, 4 max p, 5 max r
+//          3 background voxels with p > thr, 4 max p, 5 max r, 6 max |p-r|
 constexpr int MS_T = 256;
-constexpr int MS_K = 6;
+constexpr int MS_K = 7;
+constexpr unsigned MS_MAXMASK = 0x70u;
 template <class TP, class TR>
 __global__ __launch_bounds__(MS_T) void masked_stats_kernel(const TP* __restrict__ pred,
                                                             const TR* __restrict__ ref,
                                                             const uint8_t* __restrict__ mask, size_t n,
                                                             double thr, double* __restrict__ partials) {
-    double v[MS_K] = {0.0, 0.0, 0.0, 0.0, -INFINITY, -INFINITY};
+    double v[MS_K] = {0.0, 0.0, 0.0, 0.0, -INFINITY, -INFINITY, -INFINITY};
     for (size_t i = (size_t)blockIdx.x * MS_T + threadIdx.x; i < n; i += (size_t)gridDim.x * MS_T) {
         const double p = (double)pred[i], r = (double)ref[i];
         const bool fg = mask ? mask[i] != 0 : false;
@@ -216,8 +222,9 @@ __global__ __launch_bounds__(MS_T) void masked_stats_kernel(const TP* __restrict
         }
         v[4] = fmax(v[4], p);
         v[5] = fmax(v[5], r);
+        v[6] = fmax(v[6], e);
     }
-    block_reduce_store<MS_K, MS_T>(v, 0x30u, 0u, partials);
+    block_reduce_store<MS_K, MS_T>(v, MS_MAXMASK, 0u, partials);
 }
 
 static inline int stats_blocks(size_t n) {
@@ -249,7 +256,7 @@ int masked_stats_partials(size_t n) { return stats_blocks(n); }
 
 hipError_t launch_masked_stats(const void* pred, int pred_dtype, const void* ref, int ref_dtype,
                                const uint8_t* mask, size_t n, double thr, double* partials,
-                               double* out6, hipStream_t s) {
+                               double* out7, hipStream_t s) {
     const int blocks = stats_blocks(n);
     hipError_t e;
     switch (pred_dtype) {
@@ -258,7 +265,7 @@ hipError_t launch_masked_stats(const void* pred, int pred_dtype, const void* ref
         default: e = masked_stats_ref((const double*)pred, ref, ref_dtype, mask, n, thr, partials, blocks, s);
     }
     if (e != hipSuccess) return e;
-    return launch_reduce_partials(partials, blocks, MS_K, 0x30u, 0u, out6, s);
+    return launch_reduce_partials(partials, blocks, MS_K, MS_MAXMASK, 0u, out7, s);
 }
 
 // ---- min / max --------------------------------------------------------------------------------------

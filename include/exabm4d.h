@@ -14,6 +14,9 @@
  *   IntensityTransform.inverse[_float]    machine_learning/transforms.py:131-152, :261-285, :350-371, :403-411
  *   predict(): patch gather / pad         inference.py:153-174, :178-199, :202-226
  *   predict(): accumulate / normalise     inference.py:81-116
+ *   estimate_offset (np.percentile)       machine_learning/transforms.py:414-438
+ *   ssim3D, compute_mae, compute_lmax     utils/img_util.py:953-1050
+ *   evaluate_example and its parts        machine_learning/metrics.py:306-424
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, POD structs whose first field is their own sizeof
@@ -225,6 +228,48 @@ int exabm4d_tile_finalize_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
  * byte counts need the third-party codec). */
 int exabm4d_chunk_byte_histograms_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx,
                                       int cz, int cy, int cx, uint32_t* hist);
+
+/* ---- background offset + quality metrics on device (SURVEY.md section 8 "next" row f-4) --------- */
+/* Element types of the metric entry points. */
+enum { EXABM4D_DT_U16 = 0, EXABM4D_DT_F32 = 1, EXABM4D_DT_F64 = 2 };
+
+/* Exact histogram of a uint16 volume resident in HBM into hist_host[65536] (host memory; the
+ * call synchronises the context's stream).  It carries every order statistic the reference takes
+ * with numpy on the host: estimate_offset's np.percentile of the non-zero counts
+ * (machine_learning/transforms.py:414-438), the offset / all-voxel offset / median / zero
+ * fraction of scripts/estimate_background_offsets.py:31-67, the median, MAD and top percentile
+ * of machine_learning/metrics.py:352-424. */
+int exabm4d_u16_histogram_dev(exabm4d_ctx* ctx, const uint16_t* vol, size_t n, uint64_t* hist_host);
+
+/* One 16-bit digit of the order-preserving 64-bit key of the values widened to fp64
+ * (key = bits | 2^63 for non-negative values, ~bits for negative ones), or of their absolute
+ * deviation |v - center| when absdev != 0: the building block of an exact radix selection for
+ * data a 65536-bin histogram cannot hold -- np.percentile of float predictions and
+ * np.median(|raw - median|) in machine_learning/metrics.py:375-377,413-415.  Pass `digit`
+ * (0 = most significant .. 3) counts that digit of the elements whose higher digits equal
+ * `prefix`.  hist_host[65536]. */
+int exabm4d_key_histogram_dev(exabm4d_ctx* ctx, const void* vol, int dtype, size_t n, int absdev,
+                              double center, int digit, uint64_t prefix, uint64_t* hist_host);
+
+/* min and max of n elements -> out_host[2] (data range of ssim3D, utils/img_util.py:985-988). */
+int exabm4d_minmax_dev(exabm4d_ctx* ctx, const void* vol, int dtype, size_t n, double* out_host);
+
+/* Absolute-error statistics split by a foreground mask (uint8, non-zero = foreground; NULL = all
+ * background): out_host[7] = { sum |pred-ref| over foreground, the same over background,
+ * foreground voxels, background voxels with pred > thr, max pred, max ref, max |pred-ref| }.  Replaces the
+ * numpy passes of foreground_background_mae / false_bright_rate / mip_max_error
+ * (machine_learning/metrics.py:306-381) and compute_mae / compute_lmax's reductions
+ * (utils/img_util.py).  Sums are fp64; integer-valued inputs give exact results. */
+int exabm4d_masked_error_stats_dev(exabm4d_ctx* ctx, const void* pred, int pred_dtype,
+                                   const void* ref, int ref_dtype, const uint8_t* mask, size_t n,
+                                   double thr, double* out_host);
+
+/* Sum over all voxels of the SSIM map of two volumes of the same element type, cubic uniform
+ * window of `window` voxels (1..32; window i - window/2 .. i + window - window/2 - 1 per axis,
+ * scipy.ndimage.uniform_filter's "reflect" boundary), constants c1 = (0.01 L)^2, c2 = (0.03 L)^2
+ * supplied by the caller: ssim3D of utils/img_util.py:953-1003 is *sum_host / (nz ny nx). */
+int exabm4d_ssim3d_dev(exabm4d_ctx* ctx, const void* a, const void* b, int dtype, int nz, int ny,
+                       int nx, int window, double c1, double c2, double* sum_host);
 
 #ifdef __cplusplus
 }

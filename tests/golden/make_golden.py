@@ -4,7 +4,9 @@ Run in the build container only (the reference does not exist on the GPU box):
 
     PYTHONPATH=/root/reference/src python tests/golden/make_golden.py
 
-Importable subset of the reference used here: transforms, inference, unet3d.
+Importable subset of the reference used here: transforms, inference, unet3d,
+machine_learning/metrics (numpy/scipy only).  utils/img_util (ssim3D, compute_mae) is NOT importable
+here -- it imports cloudvolume, tensorstore, zarr ... at module level -- so SSIM has no fixture.
 The reference's BM4D is a third-party wheel that is not installed, so nothing here covers BM4D
 (parity unpinned for that part).
 
@@ -14,15 +16,19 @@ Host recorded in meta.json because numpy's fp32 arcsinh/sinh depend on the SIMD 
 import json
 import os
 import platform
+import sys
 
 import numpy as np
 import torch
 
 from aind_exaspim_image_compression import inference as ref_inf
+from aind_exaspim_image_compression.machine_learning import metrics as ref_metrics
 from aind_exaspim_image_compression.machine_learning import transforms as ref_tf
 from aind_exaspim_image_compression.machine_learning import unet3d as ref_unet
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from util import metric_inputs  # noqa: E402  (tests/util.py: the seeded inputs the tests regenerate)
 
 TRANSFORM_CFGS = {
     "asinh_s32": {"kind": "asinh", "params": {"offset": 0.0, "scale": 32.0}},
@@ -155,8 +161,45 @@ def make_unet():
                    "n_params": int(sum(p.numel() for p in model.parameters()))}, f, indent=1)
 
 
+def make_metrics():
+    """Reference outputs of machine_learning/metrics.py:306-424 and transforms.estimate_offset
+    for seeded examples (inputs are regenerated from the seed by metric_inputs)."""
+    out = {}
+    for seed in (0, 1):
+        pu, pf, raw, target, fg = metric_inputs(seed)
+        for pname, pred in (("u16", pu), ("f32", pf)):
+            for rname, r in (("u16", raw), ("f32", raw.astype(np.float32))):
+                tag = f"s{seed}/{pname}_{rname}"
+                ev = ref_metrics.evaluate_example(pred, r, target, fg)
+                for k, v in ev.items():
+                    out[f"{tag}/evaluate/{k}"] = np.float64(v)
+                out[f"{tag}/fb_mae"] = np.array(
+                    ref_metrics.foreground_background_mae(pred, r, fg), dtype=np.float64)
+                out[f"{tag}/mip_max_error"] = np.float64(ref_metrics.mip_max_error(pred, r))
+                out[f"{tag}/false_bright_k3"] = np.float64(
+                    ref_metrics.false_bright_rate(pred, r, fg, k=3.0))
+        for pct in (0.0, 0.1, 1.0, 50.0, 99.9, 100.0):
+            out[f"s{seed}/estimate_offset/u16/{pct}"] = np.float64(
+                ref_tf.estimate_offset(raw, percentile=pct))
+            out[f"s{seed}/estimate_offset/u16_keepzeros/{pct}"] = np.float64(
+                ref_tf.estimate_offset(raw, percentile=pct, ignore_zeros=False))
+            out[f"s{seed}/estimate_offset/f32/{pct}"] = np.float64(
+                ref_tf.estimate_offset(pf - 125.0, percentile=pct))
+    # reference tests/test_metrics.py:115-138 and tests/test_transforms.py:120-129 known answers
+    out["kat/fb_mae"] = np.array(ref_metrics.foreground_background_mae(
+        np.array([[10.0, 20.0]]), np.array([[0.0, 0.0]]), np.array([[True, False]])))
+    out["kat/mip"] = np.float64(ref_metrics.mip_max_error(np.array([1.0, 900.0]),
+                                                          np.array([0.0, 1000.0])))
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["metrics"]:
+        make_metrics()
+        print("metrics.npz written")
+        sys.exit(0)
     make_transforms()
+    make_metrics()
     make_tiling()
     make_unet()
     with open(os.path.join(HERE, "meta.json"), "w") as f:
