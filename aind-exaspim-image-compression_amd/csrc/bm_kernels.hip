@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
 
-    const int tile = blockIdx.x;
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int cx = tid & 7, cy = (tid >> 3) & 7, cz = tid >> 6;      // cz == wave index

@@ -618,7 +618,8 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
     const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int iy0 = TILE_R * ty, ix0 = TILE_R * tx;
     TileGeom tg;
     tg.nry = min(TILE_R, g.gy - iy0);
