@@ -124,7 +124,6 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return EXABM4D_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->red) (void)hipFree(ctx->red);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
     hipError_t e = hipMalloc(&ctx->scratch, bytes);
@@ -206,6 +205,7 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->red) (void)hipFree(ctx->red);
     if (ctx->win_dev) (void)hipFree(ctx->win_dev);
     if (ctx->tf_lut) (void)hipFree(ctx->tf_lut);
     for (int i = 0; i < 2 * EXABM4D_PHASE_COUNT; i++)

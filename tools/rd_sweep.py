@@ -1,0 +1,47 @@
+"""Rate-distortion sweep of the denoise -> quantise -> (rate proxy) path on one MI355X
+(BASELINE.json config 5, with the pieces this repo has): for each BM4D sigma the synthetic uint16
+volume is denoised on the device, the rate is the order-0 entropy bound of the byte-shuffled
+64^3 chunks (`shuffled_entropy_cratio`, row f-1's proxy -- NOT Blosc-zstd bytes) and the
+distortion is SSIM / MAE against the noisy input (the reference's own report, evaluate.py:105:
+ssim3D(noise, denoised)), all reduced on the GPU (row f-4).
+
+usage: python tools/rd_sweep.py [edge=512] [sigmas=0,8,16,24,32,48]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "aind-exaspim-image-compression_amd"))
+sys.path.insert(0, ROOT)
+
+from aind_exaspim_image_compression.bm4d import denoise_volume  # noqa: E402
+from aind_exaspim_image_compression.utils import img_util  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    sigmas = [float(s) for s in (sys.argv[2] if len(sys.argv) > 2 else "0,8,16,24,32,48").split(",")]
+    shape = (edge,) * 3
+    noisy = bench.synth_u16(shape, 1)
+    rows = []
+    for sigma in sigmas:
+        t0 = time.perf_counter()
+        den = noisy if sigma == 0 else denoise_volume(noisy, sigma, offset=bench.OFFSET)
+        dt = time.perf_counter() - t0
+        rows.append({
+            "sigma": sigma,
+            "entropy_cratio": img_util.shuffled_entropy_cratio(den),
+            "mae_vs_noisy": img_util.compute_mae(den, noisy),
+            "ssim_vs_noisy": float(img_util.ssim3D(noisy, den, data_range=np.max(noisy))),
+            "seconds_host_to_host": round(dt, 3),
+        })
+        print(json.dumps(rows[-1]), flush=True)
+    print(json.dumps({"volume": shape, "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()
