@@ -27,6 +27,7 @@ struct exabm4d_ctx {
     void* red = nullptr;       // metric entry points: histogram / partials / results
     size_t red_bytes = 0;
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
+    int stage_pairs = 1;       // exabm4d_set_option("stage_pairs"): two waves per group (HT stage)
     int profile = 0;           // exabm4d_set_option("profile")
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
@@ -261,6 +262,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->force_generic_bm = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "stage_pairs") == 0) {
+        ctx->stage_pairs = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "profile") == 0) {
         if (value && !ctx->ev[0])
             for (int i = 0; i < 2 * EXABM4D_PHASE_COUNT; i++) HIP_TRY(ctx, hipEventCreate(&ctx->ev[i]));
@@ -408,7 +413,7 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
     HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, num,
-                              den, ctx->stream));
+                              den, ctx->stream, ctx->stage_pairs));
     return EXABM4D_OK;
 }
 
@@ -468,7 +473,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
         HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                  sigma2, num, den, s));
+                                  sigma2, num, den, s, ctx->stage_pairs));
     }
     if (stages >= 2) {
         {
@@ -488,7 +493,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
             HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                      sigma2, num, den, s));
+                                      sigma2, num, den, s, ctx->stage_pairs));
         }
     }
     {

@@ -55,6 +55,7 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
                              uint32_t* keys, hipStream_t stream, int force_generic);
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
-                        float thr, float sigma2, float* num, float* den, hipStream_t stream);
+                        float thr, float sigma2, float* num, float* den, hipStream_t stream,
+                        int wave_pairs);
 
 }  // namespace exabm4d

@@ -338,11 +338,59 @@ __device__ __forceinline__ void ring_lock(int* lock, int lane) {
     }
     cbar();
 }
+// Same, polling without s_sleep (eight contenders: the hand-over latency matters more than the
+// issue slots the pollers take).
+__device__ __forceinline__ void ring_lock_spin(int* lock, int lane) {
+    cbar();
+    if (lane == 0) {
+        int expected = 0;
+        while (!__hip_atomic_compare_exchange_strong(lock, &expected, 1, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP))
+            expected = 0;
+    }
+    cbar();
+}
 __device__ __forceinline__ void ring_unlock(int* lock, int lane) {
     cbar();
     if (lane == 0)
         __hip_atomic_store(lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     cbar();
+}
+// Zoned variant: the lock word holds one bit per quadrant of the ring region (two row zones x two
+// column zones); a wave takes all the zones its blocks touch with ONE compare-and-swap on the
+// whole word, so nobody waits while holding a zone (no deadlock), a failed attempt never leaves
+// transient bits behind (an OR-and-back-out scheme can livelock two phase-locked waiters), and
+// blocks in different quadrants update the ring concurrently.
+__device__ __forceinline__ void ring_lock_zones(int* lock, int mask, int lane) {
+    cbar();
+    if (lane == 0) {
+        int seen = 0;                                // optimistic: nobody holds anything
+        for (;;) {
+            if (seen & mask) {                       // a zone we need is taken: back off, look again
+                __builtin_amdgcn_s_sleep(1);
+                seen = __hip_atomic_load(lock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+            }
+            // on failure `seen` is refreshed with the current word; some contender always succeeds
+            if (__hip_atomic_compare_exchange_strong(lock, &seen, seen | mask, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                break;
+        }
+    }
+    cbar();
+}
+__device__ __forceinline__ void ring_unlock_zones(int* lock, int mask, int lane) {
+    cbar();
+    if (lane == 0)
+        __hip_atomic_fetch_and(lock, ~mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cbar();
+}
+// Zone bits of a block whose first ring row / column is (by, bx) in a region of `rows` x REG.
+__device__ __forceinline__ int zone_mask(int by, int bx, int rows) {
+    const int zr = (by < rows / 2 ? 1 : 0) | (by + BLK - 1 >= rows / 2 ? 2 : 0);
+    const int zc = (bx < REG / 2 ? 1 : 0) | (bx + BLK - 1 >= REG / 2 ? 2 : 0);
+    return ((zr & 1) ? zc : 0) | ((zr & 2) ? zc << 2 : 0);
 }
 // Workgroup barrier that waits for this wave's LDS operations only (a plain __syncthreads()
 // also waits for outstanding global atomics, whose completion nobody in the kernel needs).
@@ -556,15 +604,16 @@ __device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
 }
 
 // Move ring planes [zlo, zhi) to global memory (float atomics: neighbouring tiles overlap) and
-// zero them.  Whole workgroup.
+// zero them.  Whole workgroup.  ROWS x REG voxels per plane, plane stride PSV.
+template <int ROWS = REG, int PSV = PS>
 __device__ __forceinline__ void flush_planes(f2* ring, float* __restrict__ num,
                                              float* __restrict__ den, int zlo, int zhi,
                                              const TileGeom& tg, const VolGeom& g, int nwaves) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int z = zlo + wave; z < zhi; z += nwaves) {          // one plane per wave
         const int slot = (z + 5) % NPL;
-        f2* plane = ring + slot * PS;
-        for (int rem = lane; rem < REG * REG; rem += 64) {
+        f2* plane = ring + slot * PSV;
+        for (int rem = lane; rem < ROWS * REG; rem += 64) {
             const f2 nd = plane[rem];
             if (nd.y != 0.0f) {
                 const int ryy = rem / REG, rxx = rem - ryy * REG;
@@ -579,13 +628,14 @@ __device__ __forceinline__ void flush_planes(f2* ring, float* __restrict__ num,
 }
 
 // Same, by ONE wave (the wave that closes a layer).
+template <int ROWS = REG, int PSV = PS>
 __device__ __forceinline__ void flush_planes_wave(f2* ring, float* __restrict__ num,
                                                   float* __restrict__ den, int zlo, int zhi,
                                                   const TileGeom& tg, const VolGeom& g, int lane) {
     for (int z = zlo; z < zhi; z++) {
         const int slot = (z + 5) % NPL;
-        f2* plane = ring + slot * PS;
-        for (int rem = lane; rem < REG * REG; rem += 64) {
+        f2* plane = ring + slot * PSV;
+        for (int rem = lane; rem < ROWS * REG; rem += 64) {
             const f2 nd = plane[rem];
             if (nd.y != 0.0f) {
                 const int ryy = rem / REG, rxx = rem - ryy * REG;
@@ -699,12 +749,504 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
 #endif
 }
 
+
+// =================================================================================================
+// Hard-threshold stage, two waves per group ("half groups").
+//
+// One wave alone issues a VALU instruction every 4 cycles, two waves sharing a SIMD every 2
+// (MI355X_MICROARCH.md, per-instruction constants), and the whole-group-in-registers design above
+// cannot have two waves per SIMD: a group's spectrum alone is 128 registers.  Here a group is
+// split between the two waves of a pair: wave h (0/1) transforms blocks [h K/2, (h+1) K/2), so
+// its spectrum is 64 registers and eight waves (two per SIMD) fit.  The Haar transform along the
+// group splits exactly: its first log2(K)-1 levels act inside each half, and the last level
+// combines only the two halves' approximation coefficients -- 8 values per lane -- which the
+// waves swap through their transpose buffers.  Every operation is the one the single-wave path
+// (and the oracle) performs, in the same order, so results are bit-identical up to the order of
+// the aggregation sums.  A 4x3 tile (ring 18 x 26 x 30) makes room for eight transpose buffers.
+// =================================================================================================
+constexpr int HTY = 3;                        // grid points per tile in y (x keeps TILE_R = 4)
+constexpr int HROWS = (HTY - 1) * STEP + 18;  // 26 region rows
+constexpr int HPS = 808;                      // plane stride: 780 padded to 8 (mod 32)
+constexpr int HNW = 8;                        // waves: pair p = wave >> 1, half h = wave & 1 (the waves
+                                              // of a pair sit on different SIMDs; the two waves of
+                                              // a SIMD belong to different pairs and drift apart)
+
+// Wait until *flag >= want (lane 0 spins; LDS serves the CU's instructions in arrival order, so
+// data the partner wrote before raising the flag is visible once the flag is).
+__device__ __forceinline__ void wait_flag(const int* flag, int want, int lane) {
+    cbar();
+    if (lane == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
+            __builtin_amdgcn_s_sleep(1);
+    }
+    cbar();
+}
+__device__ __forceinline__ void raise_flag(int* flag, int value, int lane) {
+    cbar();
+    if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cbar();
+}
+
+// Local part of the hard-threshold shrinkage on a half group of KH blocks: forward Haar over the
+// half, threshold and count the detail coefficients, hand back the approximation pairs.
+// Spectrum layout as in shrink_ht with the local block index: S[jp][2 kl + c] = coefficient plane
+// 2 jp + c of local block kl, so that two planes run through the Haar transform as one packed
+// stream.  (Whole-vector loads and stores only: element-wise stores into S at constant offsets
+// get merged with neighbouring accesses into wider ones, after which the array can no longer be
+// split into registers and ends up in scratch.)
+template <int KH>
+__device__ __forceinline__ void half_shrink_local(f16v (&S)[4], float thr, int& nnz, f2 (&approx)[4]) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) {
+        f16v A = S[jp];
+        f2 x[MAXG];
+#pragma unroll
+        for (int k = 0; k < KH; k++) x[k] = mk2(A[2 * k], A[2 * k + 1]);
+        haar_fwd2<KH>(x);
+        approx[jp] = x[0];
+#pragma unroll
+        for (int k = 1; k < KH; k++) {
+            const bool k0 = fabsf(x[k].x) >= thr, k1 = fabsf(x[k].y) >= thr;
+            nnz += (k0 ? 1 : 0) + (k1 ? 1 : 0);
+            A[2 * k] = k0 ? x[k].x : 0.0f;
+            A[2 * k + 1] = k1 ? x[k].y : 0.0f;
+        }
+        S[jp] = A;
+    }
+}
+// Inverse Haar over the half once the filtered approximation coefficients are known.
+template <int KH>
+__device__ __forceinline__ void half_unshrink_local(f16v (&S)[4], const f2 (&approx)[4]) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) {
+        f16v A = S[jp];
+        f2 x[MAXG];
+        x[0] = approx[jp];
+#pragma unroll
+        for (int k = 1; k < KH; k++) x[k] = mk2(A[2 * k], A[2 * k + 1]);
+        haar_inv2<KH>(x);
+#pragma unroll
+        for (int k = 0; k < KH; k++) {
+            A[2 * k] = x[k].x;
+            A[2 * k + 1] = x[k].y;
+        }
+        S[jp] = A;
+    }
+}
+
+// Wiener counterparts.  Spectrum layout S[j][2 kl + c]: coefficient plane j of local block kl,
+// c = 0 noisy, c = 1 basic estimate, so the forward Haar transforms of both run as one packed
+// stream.  Local part: Haar over the half, Wiener-filter the detail coefficients (W = e / (e +
+// sigma^2) from the basic estimate, evaluated as e * rcp: see shrink_wiener), hand back the
+// (noisy, basic) approximation pairs.  The filtered details stay in the noisy slots.
+template <int KH>
+__device__ __forceinline__ void wiener_half_local(f16v (&S)[8], float sigma2, float& sw,
+                                                  f2 (&approx)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        f16v A = S[j];
+        f2 x[MAXG];
+#pragma unroll
+        for (int k = 0; k < KH; k++) x[k] = mk2(A[2 * k], A[2 * k + 1]);
+        haar_fwd2<KH>(x);
+        approx[j] = x[0];
+#pragma unroll
+        for (int k = 1; k < KH; k++) {
+            const float e = x[k].y * x[k].y;
+            const float W = e * __builtin_amdgcn_rcpf(e + sigma2);
+            sw += W * W;
+            A[2 * k] = W * x[k].x;
+        }
+        S[j] = A;
+    }
+}
+// Inverse Haar over the half of the filtered noisy coefficients, two planes per packed stream;
+// the estimates land in the noisy slots S[j][2 kl].
+template <int KH>
+__device__ __forceinline__ void wiener_half_unlocal(f16v (&S)[8], const float (&mine)[8]) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) {
+        f16v A = S[2 * jp], B = S[2 * jp + 1];
+        f2 x[MAXG];
+        x[0] = mk2(mine[2 * jp], mine[2 * jp + 1]);
+#pragma unroll
+        for (int k = 1; k < KH; k++) x[k] = mk2(A[2 * k], B[2 * k]);
+        haar_inv2<KH>(x);
+#pragma unroll
+        for (int k = 0; k < KH; k++) {
+            A[2 * k] = x[k].x;
+            B[2 * k] = x[k].y;
+        }
+        S[2 * jp] = A;
+        S[2 * jp + 1] = B;
+    }
+}
+
+// One wave, one half of a group.  `sync` = int[2 * HNW]: ready[w], ack[w]; `seq` = exchanges this
+// pair has done so far (both waves of a pair count alike).  Returns true for the wave that
+// completes the layer.
+template <bool WIENER>
+__device__ __forceinline__ bool process_half_group(
+    const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
+    int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const DctTable& T,
+    const float (&win)[8], float thr, float sigma2, f2* ring, f2* tb, f2* partner_tb, int* lock,
+    int* sync, int wave, int& seq, int layer, int target, int lane
+#ifdef EXABM4D_STAMPS
+    , unsigned long long (&st)[16]
+#endif
+    ) {
+    constexpr int NP = WIENER ? 8 : 4;         // f2 values per lane swapped with the partner
+    const int hi = lane >> 3, lo = lane & 7;
+    STAMP(t0);
+    const int half = wave & 1, partner = wave ^ 1;
+    const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
+    const int count = __popcll(__ballot(mykey != KEY_EMPTY));
+    int K = 1;
+    while (K * 2 <= count) K *= 2;
+    const int KH = K > 1 ? K / 2 : 1;          // blocks of this half
+    const int kb = K > 1 ? half * KH : 0;      // first block of this half
+    const bool active = K > 1 || half == 0;    // a one-block group is the first wave's alone
+
+    int closer = 0;
+    if (active) {
+        f16v S[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) S[j] = (f16v)(0.0f);
+
+        int my_dz, my_dy, my_dx;
+        code_to_disp(mykey & KEY_CMASK, my_dz, my_dy, my_dx);
+        const unsigned long long my_corner =
+            lane < MAXG ? (unsigned long long)(rz + my_dz) * sz +
+                              (unsigned long long)(ry + my_dy) * sy + (unsigned long long)(rx + my_dx)
+                        : 0ull;
+        const unsigned my_corner_lo = (unsigned)my_corner, my_corner_hi = (unsigned)(my_corner >> 32);
+        auto corner_of = [&](int k) -> size_t {
+            const unsigned lo32 = __builtin_amdgcn_readlane(my_corner_lo, k);
+            const unsigned hi32 = __builtin_amdgcn_readlane(my_corner_hi, k);
+            return ((size_t)hi32 << 32) | lo32;
+        };
+        // Forward transforms of my blocks, two streams per iteration -- (noisy kl, basic kl) for
+        // Wiener, blocks (kl, kl + 1) for the hard threshold -- with the next gather in flight.
+        constexpr int kstep = WIENER ? 1 : 2;
+        float a[8], b[8], na[8] = {}, nb[8] = {};
+        f2 v2[8];
+        {
+            const size_t c0 = corner_of(kb);
+            gather8(noisy + c0, sy, sz, hi, lo, a);
+            if constexpr (WIENER)
+                gather8(basic + c0, sy, sz, hi, lo, b);
+            else
+                gather8(noisy + corner_of(kb + (KH > 1 ? 1 : 0)), sy, sz, hi, lo, b);
+        }
+        for (int kl = 0; kl < KH; kl += kstep) {
+            if (kl + kstep < KH) {
+                const size_t c0 = corner_of(kb + kl + kstep);
+                gather8(noisy + c0, sy, sz, hi, lo, na);
+                if constexpr (WIENER)
+                    gather8(basic + c0, sy, sz, hi, lo, nb);
+                else
+                    gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, nb);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+            pair_fwd(T, tb, hi, lo, v2);
+            if constexpr (WIENER) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    S[j][2 * kl] = v2[j].x;
+                    S[j][2 * kl + 1] = v2[j].y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                if (KH > 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                a[j] = na[j];
+                b[j] = nb[j];
+            }
+        }
+
+        STAMP(t1);
+        STAMP_ADD(0, t0, t1);
+        // Shrinkage: local levels, swap approximations with the partner, top level, local inverse.
+        // `tally` is this lane's share of the aggregation-weight statistic: the count of kept
+        // coefficients (hard threshold, as int bits) or the sum of squared Wiener weights.
+        int nnz = 0;
+        float sw = 0.0f;
+        f2 approx[NP];
+        if constexpr (WIENER) {
+            switch (KH) {
+                case 8: wiener_half_local<8>(S, sigma2, sw, approx); break;
+                case 4: wiener_half_local<4>(S, sigma2, sw, approx); break;
+                case 2: wiener_half_local<2>(S, sigma2, sw, approx); break;
+                default: wiener_half_local<1>(S, sigma2, sw, approx); break;
+            }
+        } else {
+            switch (KH) {
+                case 8: half_shrink_local<8>(S, thr, nnz, approx); break;
+                case 4: half_shrink_local<4>(S, thr, nnz, approx); break;
+                case 2: half_shrink_local<2>(S, thr, nnz, approx); break;
+                default: half_shrink_local<1>(S, thr, nnz, approx); break;
+            }
+        }
+        float mine[8];                 // Wiener: filtered noisy approximation of my half, per plane
+        if (K > 1) {
+            seq++;
+            // my transpose buffer is free (forward transforms done; the partner acknowledged the
+            // previous exchange before my last inverse transforms started)
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) tb[jp * 64 + lane] = approx[jp];
+            tb[NP * 64 + lane] = mk2(WIENER ? sw : __int_as_float(nnz), 0.0f);
+            raise_flag(sync + wave, seq, lane);
+            STAMP(te0);
+            wait_flag(sync + partner, seq, lane);
+            STAMP(te1);
+            STAMP_ADD(2, te0, te1);
+            f2 other[NP];
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) other[jp] = partner_tb[jp * 64 + lane];
+            const float theirs = partner_tb[NP * 64 + lane].x;
+            cbar();
+            raise_flag(sync + HNW + wave, seq, lane);          // partner may reuse its buffer
+            if constexpr (WIENER)
+                sw += theirs;
+            else
+                nnz += __float_as_int(theirs);
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) {
+                const f2 a0 = half ? other[jp] : approx[jp], a1 = half ? approx[jp] : other[jp];
+                f2 t0 = (a0 + a1) * HAAR_C, t1 = (a0 - a1) * HAAR_C;
+                if constexpr (WIENER) {
+                    const float e0 = t0.y * t0.y, e1 = t1.y * t1.y;
+                    const float W0 = e0 * __builtin_amdgcn_rcpf(e0 + sigma2);
+                    const float W1 = e1 * __builtin_amdgcn_rcpf(e1 + sigma2);
+                    sw += W0 * W0;
+                    sw += W1 * W1;
+                    const float f0 = W0 * t0.x, f1 = W1 * t1.x;
+                    mine[jp] = half ? (f0 - f1) * HAAR_C : (f0 + f1) * HAAR_C;
+                } else {
+                    const bool p0 = fabsf(t0.x) >= thr, p1 = fabsf(t0.y) >= thr;
+                    const bool q0 = fabsf(t1.x) >= thr, q1 = fabsf(t1.y) >= thr;
+                    nnz += (p0 ? 1 : 0) + (p1 ? 1 : 0) + (q0 ? 1 : 0) + (q1 ? 1 : 0);
+                    t0 = mk2(p0 ? t0.x : 0.0f, p1 ? t0.y : 0.0f);
+                    t1 = mk2(q0 ? t1.x : 0.0f, q1 ? t1.y : 0.0f);
+                    approx[jp] = half ? (t0 - t1) * HAAR_C : (t0 + t1) * HAAR_C;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) {
+                if constexpr (WIENER) {
+                    const float e = approx[jp].y * approx[jp].y;
+                    const float W = e * __builtin_amdgcn_rcpf(e + sigma2);
+                    sw += W * W;
+                    mine[jp] = W * approx[jp].x;
+                } else {
+                    const bool p0 = fabsf(approx[jp].x) >= thr, p1 = fabsf(approx[jp].y) >= thr;
+                    nnz += (p0 ? 1 : 0) + (p1 ? 1 : 0);
+                    approx[jp] = mk2(p0 ? approx[jp].x : 0.0f, p1 ? approx[jp].y : 0.0f);
+                }
+            }
+        }
+        float w;
+        if constexpr (WIENER) {
+            switch (KH) {
+                case 8: wiener_half_unlocal<8>(S, mine); break;
+                case 4: wiener_half_unlocal<4>(S, mine); break;
+                case 2: wiener_half_unlocal<2>(S, mine); break;
+                default: wiener_half_unlocal<1>(S, mine); break;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
+            w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
+        } else {
+            switch (KH) {
+                case 8: half_unshrink_local<8>(S, approx); break;
+                case 4: half_unshrink_local<4>(S, approx); break;
+                case 2: half_unshrink_local<2>(S, approx); break;
+                default: half_unshrink_local<1>(S, approx); break;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
+            w = 1.0f / (sigma2 * (float)(nnz > 1 ? nnz : 1));
+        }
+        float ww[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+
+        const int my_slot0 = (rz + my_dz + 5 + NPL) % NPL;
+        const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
+        // the partner must have read my approximations before the inverse transposes overwrite them
+        STAMP(t2);
+        STAMP_ADD(1, t1, t2);
+        if (K > 1) wait_flag(sync + HNW + partner, seq, lane);
+        if (lane == 0) {
+            while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        STAMP(t3);
+        STAMP_ADD(5, t2, t3);
+        for (int kl = 0; kl < KH; kl += 2) {
+            const int kl2 = (kl + 1 < KH) ? kl + 1 : kl;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if constexpr (WIENER)
+                    v2[j] = mk2(S[j][2 * kl], S[j][2 * kl2]);
+                else
+                    v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
+            }
+            pair_inv(T, tb, hi, lo, v2);
+            int slot_a = __builtin_amdgcn_readlane(my_slot0, kb + kl) + hi;
+            slot_a -= slot_a >= NPL ? NPL : 0;
+            const int off_a = slot_a * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl) + lo;
+            int slot_b = __builtin_amdgcn_readlane(my_slot0, kb + kl2) + hi;
+            slot_b -= slot_b >= NPL ? NPL : 0;
+            const int off_b = slot_b * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl2) + lo;
+            STAMP(tl0);
+            ring_lock(lock, lane);
+            STAMP(tl1);
+            STAMP_ADD(3, tl0, tl1);
+            {
+                f2 acc[8];
+#pragma unroll
+                for (int y = 0; y < 8; y++) acc[y] = ring[off_a + y * REG];
+#pragma unroll
+                for (int y = 0; y < 8; y++)
+                    ring[off_a + y * REG] = acc[y] + mk2(ww[y] * v2[y].x, ww[y]);
+            }
+            if (kl2 != kl) {
+                f2 acc[8];
+#pragma unroll
+                for (int y = 0; y < 8; y++) acc[y] = ring[off_b + y * REG];
+#pragma unroll
+                for (int y = 0; y < 8; y++)
+                    ring[off_b + y * REG] = acc[y] + mk2(ww[y] * v2[y].y, ww[y]);
+            }
+            ring_unlock(lock, lane);
+            STAMP(tl2);
+            STAMP_ADD(4, tl1, tl2);
+        }
+    }
+    if (!active) {
+        // An idle half still reports, but like everybody else only once the previous layer is
+        // closed: reports of layer L+1 must never be counted towards layer L.
+        if (lane == 0) {
+            while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        cbar();
+    }
+    // every wave of the pair reports once per group; all lanes take part in the atomic (a
+    // lane-0-only fetch in front of wave-wide code has been miscompiled before)
+    closer = (__hip_atomic_fetch_add(lock + 1, lane == 0 ? 1 : 0, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == target) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(closer) != 0;
+}
+
+template <bool WIENER>
+__global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
+    const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
+    const uint32_t* __restrict__ keys_all, VolGeom g, DctTable T, const float* __restrict__ win_g,
+    float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ den_all, int tiles_x,
+    int layers_per_chunk) {
+    extern __shared__ __align__(16) float lds[];
+    f2* ring = reinterpret_cast<f2*>(lds);                 // [NPL][HPS] (num, den) pairs
+    // readfirstlane: the wave index steers register indexing below and must be provably uniform
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    f2* tb = reinterpret_cast<f2*>(lds + 2 * NPL * HPS + wave * 2 * TBUF);
+    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * NPL * HPS + (wave ^ 1) * 2 * TBUF);
+    int* lock = reinterpret_cast<int*>(lds + 2 * NPL * HPS + HNW * 2 * TBUF);
+    int* sync = lock + 4;                                  // ready[HNW], ack[HNW]
+
+    const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
+    const float* __restrict__ noisy = noisy_all + voff;
+    const float* __restrict__ basic = WIENER ? basic_all + voff : nullptr;
+    float* __restrict__ num = num_all + voff;
+    float* __restrict__ den = den_all + voff;
+    const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
+    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
+
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int iy0 = HTY * ty, ix0 = TILE_R * tx;
+    TileGeom tg;
+    tg.nry = min(HTY, g.gy - iy0);
+    tg.nrx = min(TILE_R, g.gx - ix0);
+    tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
+    tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
+    const int nrefs = tg.nry * tg.nrx;
+
+    const int izb = blockIdx.y * layers_per_chunk;
+    const int ize = min(g.gz, izb + layers_per_chunk);
+
+    for (int i = threadIdx.x; i < 2 * NPL * HPS; i += HNW * 64) lds[i] = 0.0f;
+    if (threadIdx.x < 4 + 2 * HNW) lock[threadIdx.x] = threadIdx.x == 2 ? 1 : 0;
+
+    float win[8];
+    {
+        const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+        for (int y = 0; y < 8; y++) win[y] = win_g[(hi * 8 + y) * 8 + lo];
+    }
+    __syncthreads();
+
+    const int pairid = wave >> 1;
+    int seq = 0;
+#ifdef EXABM4D_STAMPS
+    unsigned long long st[16] = {};
+    const unsigned long long tk0 = stamp();
+#endif
+    for (int iz = izb; iz < ize; iz++) {
+        const int layer = iz - izb;
+        const int z0 = grid_pos(iz, g.az, g.nz);
+        for (int r = pairid; r < nrefs; r += HNW / 2) {
+            const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
+            const int iy = iy0 + jy, ix = ix0 + jx;
+            const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
+            const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
+            const bool closer = process_half_group<WIENER>(
+                noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2, ring, tb, partner_tb,
+                lock, sync, wave, seq, layer, 2 * nrefs * (layer + 1), lane
+#ifdef EXABM4D_STAMPS
+                , st
+#endif
+            );
+            if (closer) {
+                if (iz + 1 < ize) {
+                    const int zn = grid_pos(iz + 1, g.az, g.nz);
+                    flush_planes_wave<HROWS, HPS>(ring, num, den, z0 - RAD, zn - RAD, tg, g, lane);
+                }
+                cbar();
+                if (lane == 0)
+                    __hip_atomic_store(lock + 2, layer + 2, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    if (ize > izb) {
+        const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
+        flush_planes<HROWS, HPS>(ring, num, den, base, base + NPL, tg, g, HNW);
+    }
+#ifdef EXABM4D_STAMPS
+    st[7] = stamp() - tk0;
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i + (WIENER ? 8 : 0)], st[i]);
+#endif
+}
+
 constexpr int NW_HT = 4;
 constexpr int NW_WIE = 4;
 
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
-                        float thr, float sigma2, float* num, float* den, hipStream_t stream) {
+                        float thr, float sigma2, float* num, float* den, hipStream_t stream,
+                        int wave_pairs) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
     const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
@@ -716,7 +1258,30 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
     const int lpc = (g.gz + chunks - 1) / chunks;
     chunks = (g.gz + lpc - 1) / lpc;
     dim3 grid((unsigned)(tiles_y * tiles_x), (unsigned)chunks, (unsigned)batch);
-    if (basic) {
+    if (wave_pairs) {
+        const int hty = (g.gy + HTY - 1) / HTY;
+        const long long htiles = (long long)hty * tiles_x * batch;
+        int hchunks = (int)((1024 + htiles - 1) / htiles);
+        if (hchunks < 1) hchunks = 1;
+        if (hchunks > g.gz) hchunks = g.gz;
+        const int hlpc = (g.gz + hchunks - 1) / hchunks;
+        hchunks = (g.gz + hlpc - 1) / hlpc;
+        const size_t lds = sizeof(float) * (2 * NPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW);
+        const dim3 hgrid((unsigned)(hty * tiles_x), (unsigned)hchunks, (unsigned)batch);
+        if (basic) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(stage_half_kernel<true>, hgrid, dim3(HNW * 64), lds, stream, noisy, basic,
+                               keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, hlpc);
+        } else {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(stage_half_kernel<false>, hgrid, dim3(HNW * 64), lds, stream, noisy,
+                               basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, hlpc);
+        }
+    } else if (basic) {
         const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * 2 * TBUF + 4);
         hipError_t e = hipFuncSetAttribute(
             reinterpret_cast<const void*>(&stage_tile_kernel<true, NW_WIE>),

@@ -93,6 +93,44 @@ def test_hard_threshold_stage(ctx, oracle, shape):
     _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
 
 
+def _mixed_volume(shape, seed):
+    """Smooth background (groups of 16), a band of high-contrast white noise (groups of one or two
+    blocks: nothing matches), and a gradient in between (intermediate group sizes)."""
+    rng = np.random.default_rng(seed)
+    vol = rng.normal(100.0, SIGMA, shape).astype(np.float32)
+    y0, y1 = shape[1] // 3, 2 * shape[1] // 3
+    vol[:, y0:y1, :] += rng.uniform(0, 6000, (shape[0], y1 - y0, shape[2])).astype(np.float32)
+    vol[:, :, : shape[2] // 4] += np.linspace(0, 900, shape[2] // 4, dtype=np.float32)
+    return vol
+
+
+def test_half_group_kernel_equals_single_wave_kernel(ctx, oracle):
+    """The two-waves-per-group hard-threshold kernel against the one-wave-per-group kernel on a
+    volume large enough that tiles march over several z-layers, with every group size present
+    (one-block groups leave the second wave of a pair idle) -- and both against the oracle."""
+    shape = (48, 384, 400)          # 800 tiles -> two z-chunks of six layers each
+    noisy = _mixed_volume(shape, 23)
+    keys = _keys_gpu(ctx, noisy, SIGMA, 3.0)
+    sizes = np.unique((keys != 0xFFFFFFFF).sum(axis=-1))
+    assert sizes.min() <= 1 and sizes.max() == 16
+    ctx.set_option("stage_pairs", 0)
+    try:
+        num0, den0 = _stage_gpu(ctx, noisy, keys, SIGMA)
+    finally:
+        ctx.set_option("stage_pairs", 1)
+    num1, den1 = _stage_gpu(ctx, noisy, keys, SIGMA)
+    assert np.all(den1 > 0)
+    np.testing.assert_allclose(den1, den0, rtol=2e-5)
+    _assert_close_estimates(num1 / den1, num0 / den0, SIGMA)
+    sub = (slice(0, 32), slice(40, 88), slice(0, 48))          # oracle on a crop that has all regimes
+    crop = np.ascontiguousarray(noisy[sub])
+    kc = oracle.blockmatch(crop, SIGMA, 3.0)
+    num_w, den_w = oracle.stage(crop, kc, SIGMA)
+    num_g, den_g = _stage_gpu(ctx, crop, kc, SIGMA)
+    np.testing.assert_allclose(den_g, den_w, rtol=2e-5)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+
+
 def test_wiener_stage(ctx, oracle):
     shape = (40, 44, 48)
     noisy, _ = synth_volume(shape, seed=13)

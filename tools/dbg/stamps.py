@@ -5,6 +5,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "aind-exaspim-image-co
 from aind_exaspim_image_compression import _native as nat
 import bench
 ctx = nat.context(0)
+ctx.set_option("stage_pairs", int(os.environ.get("PAIRS", "1")))
 shape = (256,)*3
 vol = bench.synth_u16(shape, 1000)
 d_in = ctx.to_device(vol); d_out = ctx.alloc(vol.nbytes)
@@ -15,6 +16,11 @@ L.exabm4d_debug_stamps(out, 1)
 ctx.denoise_u16(d_in, d_out, shape, 24.0, 37.0); ctx.sync()
 L.exabm4d_debug_stamps(out, 1)
 names = ["fwd","shrink","inv","wait+lock","scatter","closer_flush","final_barrier","total"]
+if os.environ.get("PAIRS", "1") == "1":
+    hn = ["fwd", "shrink+exchange(all)", "exchange_wait", "lock_wait", "rmw", "ack+layer_wait", "-", "total"]
+    for base, lab in ((0, "HT-pairs"), (8, "WIE-pairs")):
+        tot = out[base + 7]
+        print(lab, {n: round(out[base + i]/tot,3) for i,n in enumerate(hn)}, tot)
 for base,lab in ((0,"HT"),(8,"WIE")):
     tot = out[base+7]
     print(lab, {n: round(out[base+i]/tot,3) for i,n in enumerate(names)}, "total wave-cycles(100MHz ticks?)", tot)
