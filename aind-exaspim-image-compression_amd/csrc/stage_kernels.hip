@@ -338,6 +338,24 @@ __device__ __forceinline__ void ring_lock(int* lock, int lane) {
     }
     cbar();
 }
+// Ticket lock (lock[3] = next ticket, lock[0] = now serving): first come first served, and the
+// waiters poll with plain LDS reads instead of compare-and-swap atomics.
+__device__ __forceinline__ void ring_lock_ticket(int* lock, int lane) {
+    cbar();
+    if (lane == 0) {
+        const int ticket = __hip_atomic_fetch_add(lock + 3, 1, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(lock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
+            __builtin_amdgcn_s_sleep(3);
+    }
+    cbar();
+}
+__device__ __forceinline__ void ring_unlock_ticket(int* lock, int lane) {
+    cbar();
+    if (lane == 0)
+        __hip_atomic_fetch_add(lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cbar();
+}
 // Same, polling without s_sleep (eight contenders: the hand-over latency matters more than the
 // issue slots the pollers take).
 __device__ __forceinline__ void ring_lock_spin(int* lock, int lane) {
@@ -777,7 +795,7 @@ __device__ __forceinline__ void wait_flag(const int* flag, int want, int lane) {
     cbar();
     if (lane == 0) {
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want)
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(4);
     }
     cbar();
 }
@@ -939,16 +957,24 @@ __device__ __forceinline__ bool process_half_group(
                 gather8(noisy + corner_of(kb + (KH > 1 ? 1 : 0)), sy, sz, hi, lo, b);
         }
         for (int kl = 0; kl < KH; kl += kstep) {
-            if (kl + kstep < KH) {
-                const size_t c0 = corner_of(kb + kl + kstep);
-                gather8(noisy + c0, sy, sz, hi, lo, na);
-                if constexpr (WIENER)
-                    gather8(basic + c0, sy, sz, hi, lo, nb);
-                else
+            if constexpr (!WIENER) {
+                if (kl + kstep < KH) {
+                    gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, na);
                     gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, nb);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+            if constexpr (WIENER) {
+                // Wiener holds two spectra (128 registers): no room to keep the next gather in
+                // flight across the transform; it is issued right after this pair has left a / b
+                // and overlaps the transform's LDS round trips and the partner wave instead.
+                if (kl + 1 < KH) {
+                    const size_t c0 = corner_of(kb + kl + 1);
+                    gather8(noisy + c0, sy, sz, hi, lo, a);
+                    gather8(basic + c0, sy, sz, hi, lo, b);
+                }
+            }
             pair_fwd(T, tb, hi, lo, v2);
             if constexpr (WIENER) {
 #pragma unroll
@@ -964,10 +990,12 @@ __device__ __forceinline__ bool process_half_group(
                     for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
                 }
             }
+            if constexpr (!WIENER) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                a[j] = na[j];
-                b[j] = nb[j];
+                for (int j = 0; j < 8; j++) {
+                    a[j] = na[j];
+                    b[j] = nb[j];
+                }
             }
         }
 
@@ -1087,7 +1115,7 @@ __device__ __forceinline__ bool process_half_group(
         if (K > 1) wait_flag(sync + HNW + partner, seq, lane);
         if (lane == 0) {
             while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(12);
         }
         STAMP(t3);
         STAMP_ADD(5, t2, t3);
@@ -1108,7 +1136,7 @@ __device__ __forceinline__ bool process_half_group(
             slot_b -= slot_b >= NPL ? NPL : 0;
             const int off_b = slot_b * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl2) + lo;
             STAMP(tl0);
-            ring_lock(lock, lane);
+            ring_lock_ticket(lock, lane);
             STAMP(tl1);
             STAMP_ADD(3, tl0, tl1);
             {
@@ -1127,7 +1155,7 @@ __device__ __forceinline__ bool process_half_group(
                 for (int y = 0; y < 8; y++)
                     ring[off_b + y * REG] = acc[y] + mk2(ww[y] * v2[y].y, ww[y]);
             }
-            ring_unlock(lock, lane);
+            ring_unlock_ticket(lock, lane);
             STAMP(tl2);
             STAMP_ADD(4, tl1, tl2);
         }
@@ -1137,7 +1165,7 @@ __device__ __forceinline__ bool process_half_group(
         // closed: reports of layer L+1 must never be counted towards layer L.
         if (lane == 0) {
             while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(12);
         }
         cbar();
     }
@@ -1217,6 +1245,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 #endif
             );
             if (closer) {
+                STAMP(tf0);
                 if (iz + 1 < ize) {
                     const int zn = grid_pos(iz + 1, g.az, g.nz);
                     flush_planes_wave<HROWS, HPS>(ring, num, den, z0 - RAD, zn - RAD, tg, g, lane);
@@ -1225,6 +1254,8 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
                 if (lane == 0)
                     __hip_atomic_store(lock + 2, layer + 2, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                STAMP(tf1);
+                STAMP_ADD(6, tf0, tf1);
             }
         }
     }

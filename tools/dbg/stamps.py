@@ -17,7 +17,7 @@ ctx.denoise_u16(d_in, d_out, shape, 24.0, 37.0); ctx.sync()
 L.exabm4d_debug_stamps(out, 1)
 names = ["fwd","shrink","inv","wait+lock","scatter","closer_flush","final_barrier","total"]
 if os.environ.get("PAIRS", "1") == "1":
-    hn = ["fwd", "shrink+exchange(all)", "exchange_wait", "lock_wait", "rmw", "ack+layer_wait", "-", "total"]
+    hn = ["fwd", "shrink+exchange(all)", "exchange_wait", "lock_wait", "rmw", "ack+layer_wait", "closer_flush", "total"]
     for base, lab in ((0, "HT-pairs"), (8, "WIE-pairs")):
         tot = out[base + 7]
         print(lab, {n: round(out[base + i]/tot,3) for i,n in enumerate(hn)}, tot)
