@@ -356,59 +356,11 @@ __device__ __forceinline__ void ring_unlock_ticket(int* lock, int lane) {
         __hip_atomic_fetch_add(lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     cbar();
 }
-// Same, polling without s_sleep (eight contenders: the hand-over latency matters more than the
-// issue slots the pollers take).
-__device__ __forceinline__ void ring_lock_spin(int* lock, int lane) {
-    cbar();
-    if (lane == 0) {
-        int expected = 0;
-        while (!__hip_atomic_compare_exchange_strong(lock, &expected, 1, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP))
-            expected = 0;
-    }
-    cbar();
-}
 __device__ __forceinline__ void ring_unlock(int* lock, int lane) {
     cbar();
     if (lane == 0)
         __hip_atomic_store(lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     cbar();
-}
-// Zoned variant: the lock word holds one bit per quadrant of the ring region (two row zones x two
-// column zones); a wave takes all the zones its blocks touch with ONE compare-and-swap on the
-// whole word, so nobody waits while holding a zone (no deadlock), a failed attempt never leaves
-// transient bits behind (an OR-and-back-out scheme can livelock two phase-locked waiters), and
-// blocks in different quadrants update the ring concurrently.
-__device__ __forceinline__ void ring_lock_zones(int* lock, int mask, int lane) {
-    cbar();
-    if (lane == 0) {
-        int seen = 0;                                // optimistic: nobody holds anything
-        for (;;) {
-            if (seen & mask) {                       // a zone we need is taken: back off, look again
-                __builtin_amdgcn_s_sleep(1);
-                seen = __hip_atomic_load(lock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
-            }
-            // on failure `seen` is refreshed with the current word; some contender always succeeds
-            if (__hip_atomic_compare_exchange_strong(lock, &seen, seen | mask, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                break;
-        }
-    }
-    cbar();
-}
-__device__ __forceinline__ void ring_unlock_zones(int* lock, int mask, int lane) {
-    cbar();
-    if (lane == 0)
-        __hip_atomic_fetch_and(lock, ~mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    cbar();
-}
-// Zone bits of a block whose first ring row / column is (by, bx) in a region of `rows` x REG.
-__device__ __forceinline__ int zone_mask(int by, int bx, int rows) {
-    const int zr = (by < rows / 2 ? 1 : 0) | (by + BLK - 1 >= rows / 2 ? 2 : 0);
-    const int zc = (bx < REG / 2 ? 1 : 0) | (bx + BLK - 1 >= REG / 2 ? 2 : 0);
-    return ((zr & 1) ? zc : 0) | ((zr & 2) ? zc << 2 : 0);
 }
 // Workgroup barrier that waits for this wave's LDS operations only (a plain __syncthreads()
 // also waits for outstanding global atomics, whose completion nobody in the kernel needs).

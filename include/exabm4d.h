@@ -109,7 +109,9 @@ int exabm4d_sync(exabm4d_ctx* ctx);
 int exabm4d_default_params(exabm4d_params* p);
 /* Diagnostic switches. "force_generic_bm" = 1 routes every reference block through the
  * one-wave-per-block matching kernel (normally used only for grid points that are not a
- * multiple of 4); the parity tests use it to check the two kernels against each other. */
+ * multiple of 4); the parity tests use it to check the two kernels against each other.
+ * "stage_pairs" = 0 selects the one-wave-per-group stage kernels instead of the default
+ * two-waves-per-group ones (same arithmetic; kept as a cross-check). */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
 /* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
  * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and

@@ -1,0 +1,68 @@
+"""Stress the two-waves-per-group stage kernels on volumes with every group-size regime at
+multi-layer scale, against the one-wave-per-group kernels (same library, option "stage_pairs").
+
+usage: python tools/stress_stage.py [edge=384]   (wrap in `timeout`: a hang is the failure mode)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "aind-exaspim-image-compression_amd"))
+sys.path.insert(0, ROOT)
+
+from aind_exaspim_image_compression import _native  # noqa: E402
+import bench  # noqa: E402
+
+
+def volumes(edge):
+    rng = np.random.default_rng(0)
+    for seed in (1, 2, 3):
+        yield f"synthetic seed {seed}", bench.synth_u16((edge,) * 3, seed)
+    v = bench.synth_u16((edge,) * 3, 4).astype(np.int64)
+    v[:, edge // 3: edge // 2, :] += rng.integers(0, 6000, (edge, edge // 2 - edge // 3, edge))
+    yield "white-noise band (one-block groups)", np.clip(v, 0, 65535).astype(np.uint16)
+    v = bench.synth_u16((edge,) * 3, 5)
+    v[: edge // 4] = 0
+    v[:, :, -edge // 5:] = 0
+    yield "zero padding", v
+    v = np.zeros((edge,) * 3, np.uint16)
+    v[edge // 2 - 20: edge // 2 + 20, 10:50, 30:90] = 5000
+    yield "mostly empty", v
+    v = rng.integers(0, 65536, (edge,) * 3).astype(np.uint16)
+    yield "full-range white noise", v
+    yield "thin slab", bench.synth_u16((24, edge, edge), 6)
+    yield "odd extents", bench.synth_u16((edge - 3, edge - 5, edge - 7), 7)
+
+
+def main():
+    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+    ctx = _native.context(0)
+    for name, vol in volumes(edge):
+        outs = []
+        for pairs in (1, 0):
+            ctx.set_option("stage_pairs", pairs)
+            d_in = ctx.to_device(vol)
+            d_out = ctx.alloc(vol.nbytes)
+            t0 = time.perf_counter()
+            ctx.denoise_u16(d_in, d_out, vol.shape, bench.SIGMA, bench.OFFSET)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            outs.append((d_out.download(vol.shape, np.uint16), dt))
+            d_in.free()
+            d_out.free()
+        diff = np.abs(outs[0][0].astype(np.int32) - outs[1][0].astype(np.int32))
+        # stage-2 matching runs on the stage-1 estimate, whose last bits depend on the order of the
+        # aggregation atomics: isolated voxels may move by a few counts between any two runs
+        ok = diff.max() <= 4 and np.mean(diff > 0) < 2e-3 and np.mean(diff > 1) < 1e-6
+        print(f"{name:40s} {vol.shape} pairs {outs[0][1]*1e3:7.1f} ms  single {outs[1][1]*1e3:7.1f} ms  "
+              f"max|d| {diff.max()}  frac {np.mean(diff > 0):.1e}  {'OK' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            sys.exit(1)
+    ctx.set_option("stage_pairs", 1)
+    print("all volumes agree")
+
+
+if __name__ == "__main__":
+    main()
