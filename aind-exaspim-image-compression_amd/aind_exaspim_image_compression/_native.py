@@ -111,6 +111,9 @@ SIGNATURES = {
     "exabm4d_tile_accumulate_dev": (_I, [_CTX, c_vp, c_i32p, _I, _I, _I, c_vp, c_vp, _I, _I, _I]),
     "exabm4d_tile_finalize_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, c_vp, _SZ]),
     "exabm4d_chunk_byte_histograms_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, c_vp]),
+    "exabm4d_dctq_forward_dev": (_I, [_CTX, c_vp, _I, _I, _I, ctypes.c_float, c_vp]),
+    "exabm4d_dctq_inverse_dev": (_I, [_CTX, c_vp, _I, _I, _I, ctypes.c_float, c_vp]),
+    "exabm4d_i32_symbol_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
     "exabm4d_u16_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
     "exabm4d_key_histogram_dev": (_I, [_CTX, c_vp, _I, _SZ, _I, ctypes.c_double, _I,
                                        ctypes.c_uint64, c_vp]),
@@ -377,8 +380,25 @@ class Context:
                                                             int(chunk[0]), int(chunk[1]),
                                                             int(chunk[2]), _ptr(hist)))
 
+    # -- transform quantiser (row f-1) ---------------------------------------------------------
+    def dctq_forward(self, vol, shape, q, idx):
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_dctq_forward_dev(self.handle, _ptr(vol), nz, ny, nx, float(q),
+                                                   _ptr(idx)))
+
+    def dctq_inverse(self, idx, shape, q, vol):
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_dctq_inverse_dev(self.handle, _ptr(idx), nz, ny, nx, float(q),
+                                                   _ptr(vol)))
+
     # -- background offset + quality metrics (row f-4); inputs on device, scalars to the host ----
     DTYPES = {np.dtype(np.uint16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+    def i32_symbol_histogram(self, idx, n):
+        hist = np.empty(65536, dtype=np.uint64)
+        self._check(lib().exabm4d_i32_symbol_histogram_dev(self.handle, _ptr(idx), n,
+                                                           hist.ctypes.data_as(c_vp)))
+        return hist
 
     def u16_histogram(self, vol, n):
         hist = np.empty(65536, dtype=np.uint64)

@@ -680,6 +680,28 @@ int exabm4d_chunk_byte_histograms_dev(exabm4d_ctx* ctx, const uint16_t* vol, int
     return EXABM4D_OK;
 }
 
+// ---- transform quantiser (row f-1) ------------------------------------------------------
+int exabm4d_dctq_forward_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx, float q,
+                             int32_t* idx) {
+    if (!ctx || !vol || !idx) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (nz < 1 || ny < 1 || nx < 1 || !(q > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "bad sizes / step");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float dct[64], win[512];
+    make_tables(0.0, dct, win);            // the DCT table does not depend on the window's beta
+    HIP_TRY(ctx, launch_dctq_forward(vol, nz, ny, nx, dct, q, idx, ctx->stream));
+    return EXABM4D_OK;
+}
+int exabm4d_dctq_inverse_dev(exabm4d_ctx* ctx, const int32_t* idx, int nz, int ny, int nx, float q,
+                             uint16_t* vol) {
+    if (!ctx || !vol || !idx) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (nz < 1 || ny < 1 || nx < 1 || !(q > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "bad sizes / step");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float dct[64], win[512];
+    make_tables(0.0, dct, win);
+    HIP_TRY(ctx, launch_dctq_inverse(idx, nz, ny, nx, dct, q, vol, ctx->stream));
+    return EXABM4D_OK;
+}
+
 // ---- background offset + quality metrics (row f-4) ---------------------------------------------------
 static int metric_scratch(exabm4d_ctx* ctx, size_t bytes) {
     if (ctx->red_bytes >= bytes) return EXABM4D_OK;
@@ -703,6 +725,14 @@ int exabm4d_u16_histogram_dev(exabm4d_ctx* ctx, const uint16_t* vol, size_t n, u
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = metric_scratch(ctx, 65536 * sizeof(uint64_t))) return rc;
     HIP_TRY(ctx, launch_hist_u16(vol, n, (unsigned long long*)ctx->red, ctx->stream));
+    return metric_fetch(ctx, hist_host, ctx->red, 65536 * sizeof(uint64_t));
+}
+
+int exabm4d_i32_symbol_histogram_dev(exabm4d_ctx* ctx, const int32_t* idx, size_t n, uint64_t* hist_host) {
+    if (!ctx || !hist_host || (!idx && n)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = metric_scratch(ctx, 65536 * sizeof(uint64_t))) return rc;
+    HIP_TRY(ctx, launch_hist_i32_clamped(idx, n, (unsigned long long*)ctx->red, ctx->stream));
     return metric_fetch(ctx, hist_host, ctx->red, 65536 * sizeof(uint64_t));
 }
 

@@ -38,6 +38,11 @@ hipError_t launch_tile_finalize(const TfDev& t, const float* acc, const float* w
                                 size_t n, hipStream_t s);
 hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz, int cy, int cx,
                              uint32_t* hist, hipStream_t s);
+hipError_t launch_dctq_forward(const uint16_t* vol, int nz, int ny, int nx, const float* dct64, float q,
+                               int32_t* idx, hipStream_t s);
+hipError_t launch_dctq_inverse(const int32_t* idx, int nz, int ny, int nx, const float* dct64, float q,
+                               uint16_t* vol, hipStream_t s);
+hipError_t launch_hist_i32_clamped(const int32_t* idx, size_t n, unsigned long long* hist, hipStream_t s);
 hipError_t launch_hist_u16(const uint16_t* vol, size_t n, unsigned long long* hist, hipStream_t s);
 hipError_t launch_hist_key(const void* vol, int dtype, size_t n, int absdev, double center, int digit,
                            unsigned long long prefix, unsigned long long* hist, hipStream_t s);

@@ -35,6 +35,19 @@ struct KeyU16 {
     }
     __device__ uint32_t one(size_t i) const { return p[i]; }
 };
+// int32 quantisation indices as the symbols of an escape code: values in [-32767, 32767] keep their
+// own bin (value + 32768), everything beyond shares bin 0, the escape symbol.
+struct KeyI32Symbol {
+    const int32_t* p;
+    static constexpr int PER = 4;
+    __device__ static uint32_t sym(int v) { return (v < -32767 || v > 32767) ? 0u : (uint32_t)(v + 32768); }
+    __device__ void load(size_t vec, uint32_t (&k)[8]) const {
+        const int4 v = reinterpret_cast<const int4*>(p)[vec];
+        k[0] = sym(v.x); k[1] = sym(v.y); k[2] = sym(v.z); k[3] = sym(v.w);
+        k[4] = k[5] = k[6] = k[7] = 0xFFFFFFFFu;
+    }
+    __device__ uint32_t one(size_t i) const { return sym(p[i]); }
+};
 // Order-preserving 64-bit key of a value widened to fp64 (optionally of its absolute deviation
 // from a centre): ascending unsigned keys <=> ascending values.  A radix selection over its four
 // 16-bit digits gives exact order statistics of any element type: pass d counts digit d of the
@@ -130,6 +143,9 @@ static hipError_t launch_hist(Key key, size_t n, bool aligned, unsigned long lon
 
 hipError_t launch_hist_u16(const uint16_t* vol, size_t n, unsigned long long* hist, hipStream_t s) {
     return launch_hist(KeyU16{vol}, n, ((uintptr_t)vol & 15u) == 0, hist, s);
+}
+hipError_t launch_hist_i32_clamped(const int32_t* idx, size_t n, unsigned long long* hist, hipStream_t s) {
+    return launch_hist(KeyI32Symbol{idx}, n, ((uintptr_t)idx & 15u) == 0, hist, s);
 }
 hipError_t launch_hist_key(const void* vol, int dtype, size_t n, int absdev, double center, int digit,
                            unsigned long long prefix, unsigned long long* hist, hipStream_t s) {

@@ -19,12 +19,9 @@
 // All DCT arithmetic is the even/odd-folded 4-term fmaf chain of DESIGN.md 3.5 and is
 // bit-identical to the oracle; only the order of the atomic sums differs.
 #include "exabm4d_kernels.h"
+#include "dct_pairs.h"
 
 namespace exabm4d {
-
-struct DctTable {
-    float d[64];  // [u][n], orthonormal DCT-II, rounded once from double (exabm4d_tables)
-};
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -49,9 +46,6 @@ constexpr int TILE_R = 4;                 // grid points per tile edge in y and 
 constexpr int REG = 30;                   // ring region edge: 12 (3 steps) + 8 (block) + 2*5
 constexpr int PS = 904;                   // ring plane stride: 900 padded to 8 (mod 32)
 constexpr int NPL = 18;                   // ring planes: z0-5 .. z0+12
-constexpr int TBUF = 640;                 // per-wave transpose buffer: [8][8][8] float2, strides below
-constexpr int TSI = 80, TSJ = 10;         // (found by enumeration) make the b64 writes and b128 reads
-                                          // of all four transposes bank-conflict-free but one 2-way write
 constexpr float HAAR_C = 0.70710678118654752440f;
 
 __device__ __forceinline__ float chain4(float c0, float v0, float c1, float v1, float c2, float v2,
@@ -124,73 +118,6 @@ __device__ __forceinline__ void haar_inv(f16v& v) {
     }
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-// (In C++ `(f2)(a, b)` is a cast of a comma expression, not a vector literal.)
-__device__ __forceinline__ f2 mk2(float a, float b) {
-    f2 r;
-    r.x = a;
-    r.y = b;
-    return r;
-}
-
-// Two independent streams (.x, .y) through one packed-fp32 instruction stream: v_pk_fma_f32 etc.
-// do both components with one issue slot, which is what matters at one wave per SIMD.  Each
-// component is an ordinary IEEE fp32 operation, so results stay bit-identical to the oracle.
-__device__ __forceinline__ f2 chain4p(float c0, f2 v0, float c1, f2 v1, float c2, f2 v2, float c3,
-                                      f2 v3) {
-    f2 t = v0 * c0;
-    t = __builtin_elementwise_fma((f2)(c1), v1, t);
-    t = __builtin_elementwise_fma((f2)(c2), v2, t);
-    t = __builtin_elementwise_fma((f2)(c3), v3, t);
-    return t;
-}
-__device__ __forceinline__ void dct8_fwd2(const DctTable& T, f2 (&v)[8]) {
-    f2 s[4], d[4], o[8];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        s[n] = v[n] + v[7 - n];
-        d[n] = v[n] - v[7 - n];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const float* c = T.d + u * 8;
-        o[u] = (u & 1) ? chain4p(c[0], d[0], c[1], d[1], c[2], d[2], c[3], d[3])
-                       : chain4p(c[0], s[0], c[1], s[1], c[2], s[2], c[3], s[3]);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = o[u];
-}
-__device__ __forceinline__ void dct8_inv2(const DctTable& T, f2 (&v)[8]) {
-    f2 x[8];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        const f2 e = chain4p(T.d[0 * 8 + n], v[0], T.d[2 * 8 + n], v[2], T.d[4 * 8 + n], v[4],
-                             T.d[6 * 8 + n], v[6]);
-        const f2 o = chain4p(T.d[1 * 8 + n], v[1], T.d[3 * 8 + n], v[3], T.d[5 * 8 + n], v[5],
-                             T.d[7 * 8 + n], v[7]);
-        x[n] = e + o;
-        x[7 - n] = e - o;
-    }
-#pragma unroll
-    for (int n = 0; n < 8; n++) v[n] = x[n];
-}
-
-// The transpose buffer is private to one wave and LDS executes a wave's instructions in issue
-// order, so between its writes and its (cross-lane) reads only the COMPILER must be kept from
-// reordering; no s_waitcnt or barrier is needed.
-__device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }
-
-__device__ __forceinline__ void load8p(const f2* p, f2 (&v)[8]) {
-    const f4* q = reinterpret_cast<const f4*>(p);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const f4 t = q[i];
-        v[2 * i] = mk2(t.x, t.y);
-        v[2 * i + 1] = mk2(t.z, t.w);
-    }
-}
-
 // Issue the gather of one block (corner `src`) in layout L1 (hi = z, lo = x, regs y).
 __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy, size_t sz, int hi,
                                         int lo, float (&v)[8]) {
@@ -199,41 +126,6 @@ __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy
     const unsigned loff = (unsigned)hi * (unsigned)sz + (unsigned)lo;
 #pragma unroll
     for (int y = 0; y < 8; y++) v[y] = (src + (size_t)y * sy)[loff];
-}
-
-// 3-D DCT of TWO blocks at once (streams .x / .y; the transpose buffer holds float2 elements).
-// In: layout L1, out: L3.
-__device__ __forceinline__ void pair_fwd(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
-    dct8_fwd2(T, v);                                             // along y
-#pragma unroll
-    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = v[y];  // buffer [z][y][x]
-    cbar();
-    load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
-    cbar();
-    dct8_fwd2(T, v);                                             // along x
-#pragma unroll
-    for (int x = 0; x < 8; x++) tb[x * TSI + lo * TSJ + hi] = v[x];  // buffer [x][y][z]
-    cbar();
-    load8p(tb + hi * TSI + lo * TSJ, v);                         // L3: hi = x, lo = y, regs z
-    cbar();
-    dct8_fwd2(T, v);                                             // along z
-}
-
-// Inverse of pair_fwd: L3 spectra in, spatial blocks in layout L1 out.
-__device__ __forceinline__ void pair_inv(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
-    dct8_inv2(T, v);                                             // along z (L3: hi = x, lo = y)
-#pragma unroll
-    for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = v[z];  // buffer [z][y][x]
-    cbar();
-    load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
-    cbar();
-    dct8_inv2(T, v);                                             // along x
-#pragma unroll
-    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = v[x];  // buffer [z][x][y]
-    cbar();
-    load8p(tb + hi * TSI + lo * TSJ, v);                         // L1: hi = z, lo = x, regs y
-    cbar();
-    dct8_inv2(T, v);                                             // along y
 }
 
 typedef float f32v __attribute__((ext_vector_type(32)));

@@ -231,6 +231,23 @@ int exabm4d_tile_finalize_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
 int exabm4d_chunk_byte_histograms_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx,
                                       int cz, int cy, int cx, uint32_t* hist);
 
+/* Transform quantiser of the encode half (BASELINE.json config 5 "3D wavelet/DCT quantise"; the
+ * reference has no such step -- it hands the denoised uint16 volume to Blosc / JPEG-XL,
+ * evaluate.py:40 -- so the specification is this repo's): non-overlapping 8^3
+ * blocks (edge voxels replicated), orthonormal 3-D DCT with the arithmetic of the BM4D
+ * transforms, idx = (int32) rintf(c / q) (clamped to +-2^30).  idx receives ceil(nz/8) *
+ * ceil(ny/8) * ceil(nx/8) blocks of 512 coefficients (block raster, then (uz, uy, ux) raster).
+ * The inverse dequantises, inverts, clamps to [0, 65535] and rounds half to even.  Indices are
+ * bit-exact against the oracle (orc_dctq_forward). */
+int exabm4d_dctq_forward_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx, float q,
+                             int32_t* idx);
+int exabm4d_dctq_inverse_dev(exabm4d_ctx* ctx, const int32_t* idx, int nz, int ny, int nx, float q,
+                             uint16_t* vol);
+/* Symbol histogram of n quantisation indices for an escape-coded rate estimate: bin v + 32768
+ * for -32767 <= v <= 32767, bin 0 (the escape symbol) for everything else.  hist_host[65536]. */
+int exabm4d_i32_symbol_histogram_dev(exabm4d_ctx* ctx, const int32_t* idx, size_t n,
+                                     uint64_t* hist_host);
+
 /* ---- background offset + quality metrics on device (SURVEY.md section 8 "next" row f-4) --------- */
 /* Element types of the metric entry points. */
 enum { EXABM4D_DT_U16 = 0, EXABM4D_DT_F32 = 1, EXABM4D_DT_F64 = 2 };

@@ -52,6 +52,10 @@ def lib():
                                c_f, c_f]
         L.orc_bm4d_u16.argtypes = [u16p, u16p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_d,
                                    c_int]
+        L.orc_dctq_forward.argtypes = [u16p, c_int, c_int, c_int, c_f, i32p]
+        L.orc_dctq_inverse.argtypes = [i32p, c_int, c_int, c_int, c_f, u16p]
+        L.orc_dctq_forward.restype = None
+        L.orc_dctq_inverse.restype = None
         L.orc_num_threads.restype = c_int
         for name in ("orc_grid_positions", "orc_tables", "orc_blockmatch", "orc_group_transform",
                      "orc_stage", "orc_normalize", "orc_bm4d", "orc_bm4d_u16"):
@@ -157,6 +161,24 @@ def bm4d_u16(vol, sigma, offset, stages=2, **kw):
     lib().orc_bm4d_u16(_p(vol, ctypes.c_uint16), _p(out, ctypes.c_uint16), nz, ny, nx,
                        float(sigma), float(offset), float(p["lambda_ht"]), float(p["c_match_ht"]),
                        float(p["c_match_wie"]), float(p["kaiser_beta"]), int(stages))
+    return out
+
+
+def dctq_forward(vol_u16, q):
+    """DESIGN.md 3.10 transform quantiser -> int32 indices [nbz, nby, nbx, 512]."""
+    v = np.ascontiguousarray(vol_u16, dtype=np.uint16)
+    nz, ny, nx = v.shape
+    nb = [-(-n // 8) for n in v.shape]
+    out = np.empty((nb[0], nb[1], nb[2], 512), dtype=np.int32)
+    lib().orc_dctq_forward(_p(v, ctypes.c_uint16), nz, ny, nx, float(q), _p(out, ctypes.c_int32))
+    return out
+
+
+def dctq_inverse(idx, shape, q):
+    i = np.ascontiguousarray(idx, dtype=np.int32)
+    nz, ny, nx = shape
+    out = np.empty(shape, dtype=np.uint16)
+    lib().orc_dctq_inverse(_p(i, ctypes.c_int32), nz, ny, nx, float(q), _p(out, ctypes.c_uint16))
     return out
 
 

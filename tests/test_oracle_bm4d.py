@@ -98,3 +98,22 @@ def test_crop_invariance(oracle):
     full = oracle.bm4d(vol, SIGMA)
     crop = oracle.bm4d(vol[:, :, 4:116], SIGMA)
     np.testing.assert_allclose(crop[:, :, 48:-48], full[:, :, 52:-52], rtol=1e-4, atol=1e-3)
+
+
+def test_dct_quantiser_oracle_properties(oracle):
+    """DESIGN.md 3.10 on the CPU: orthonormal transform (energy preserved up to quantisation),
+    step 1 reproduces the volume to within one count, edge blocks replicate the last voxel."""
+    rng = np.random.default_rng(3)
+    vol = np.clip(rng.normal(400, 80, (20, 17, 33)), 0, 65535).astype(np.uint16)
+    idx = oracle.dctq_forward(vol, 1.0)
+    assert idx.shape == (3, 3, 5, 512) and idx.dtype == np.int32
+    rec = oracle.dctq_inverse(idx, vol.shape, 1.0)
+    assert np.abs(rec.astype(np.int32) - vol.astype(np.int32)).max() <= 1
+    full = np.full((8, 8, 8), 1000, np.uint16)
+    dc = oracle.dctq_forward(full, 1.0)[0, 0, 0]
+    assert dc[0] == int(round(1000 * 512 ** 0.5)) and np.count_nonzero(dc[1:]) == 0
+    # a 1-voxel volume is one replicated block: only the DC coefficient
+    one = oracle.dctq_forward(np.array([[[77]]], np.uint16), 2.0)
+    assert one.shape == (1, 1, 1, 512) and np.count_nonzero(one[0, 0, 0, 1:]) == 0
+    coarse = oracle.dctq_inverse(oracle.dctq_forward(vol, 32.0), vol.shape, 32.0)
+    assert 1.0 < np.abs(coarse.astype(np.float64) - vol).mean() < 32.0

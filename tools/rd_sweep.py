@@ -5,6 +5,9 @@ volume is denoised on the device, the rate is the order-0 entropy bound of the b
 distortion is SSIM / MAE against the noisy input (the reference's own report, evaluate.py:105:
 ssim3D(noise, denoised)), all reduced on the GPU (row f-4).
 
+A second sweep quantises the sigma = 24 result with the block-DCT quantiser of row f-1 at several
+steps: order-0 entropy of the indices in bits per voxel against MAE / max error / SSIM.
+
 usage: python tools/rd_sweep.py [edge=512] [sigmas=0,8,16,24,32,48]"""
 import json
 import os
@@ -18,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "aind-exaspim-image-compression_amd"))
 sys.path.insert(0, ROOT)
 
 from aind_exaspim_image_compression.bm4d import denoise_volume  # noqa: E402
-from aind_exaspim_image_compression.utils import img_util  # noqa: E402
+from aind_exaspim_image_compression.utils import dct_quant, img_util  # noqa: E402
 import bench  # noqa: E402
 
 
@@ -40,7 +43,16 @@ def main():
             "seconds_host_to_host": round(dt, 3),
         })
         print(json.dumps(rows[-1]), flush=True)
-    print(json.dumps({"volume": shape, "rows": rows}))
+    # second axis of the sweep: the transform quantiser on the sigma = 24 result
+    den = denoise_volume(noisy, 24.0, offset=bench.OFFSET)
+    qrows = []
+    for q in (1.0, 2.0, 4.0, 8.0, 16.0, 32.0):
+        rd = dct_quant.rate_distortion(den, q)
+        rec = dct_quant.reconstruct(dct_quant.quantise(den, q), den.shape, q)
+        rd["ssim_vs_denoised"] = float(img_util.ssim3D(den, rec, data_range=np.max(den)))
+        qrows.append(rd)
+        print(json.dumps(rd), flush=True)
+    print(json.dumps({"volume": shape, "rows": rows, "dct_quantiser_on_sigma24": qrows}))
 
 
 if __name__ == "__main__":
