@@ -324,6 +324,74 @@ hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz
     return hipGetLastError();
 }
 
+// ---- denominator of the aggregation as a convolution (stage_kernels.hip, two-waves-per-group) ----
+// out(i) = sum_{t=0..7} k[t] * in(i - t) along one axis: a block corner c with weight w spreads
+// w * k[t] over voxels c .. c + 7.  Fixed summation order, so the result is deterministic.
+struct Win1D {
+    float k[8];
+};
+// along x: one thread per output voxel, its 8 inputs are neighbours in a row (L1 hits)
+__global__ __launch_bounds__(EW_THREADS) void conv8_x_kernel(const float* __restrict__ in,
+                                                             float* __restrict__ out, size_t n, int nx,
+                                                             Win1D w) {
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * EW_THREADS) {
+        const int x = (int)(i % (size_t)nx);
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (t <= x) acc = fmaf(w.k[t], in[i - t], acc);
+        out[i] = acc;
+    }
+}
+// along y or z: one thread per line (lanes along x: coalesced), marching with the last 8 inputs
+// in registers, so every input is read once.  Line (o, i): base = o * extent * inner + i,
+// element stride `inner`.
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __restrict__ in,
+                                                                float* __restrict__ out, size_t nlines,
+                                                                size_t inner, int extent, Win1D w) {
+    for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
+         l += (size_t)gridDim.x * EW_THREADS) {
+        const size_t o = l / inner, i = l - o * inner;
+        const size_t base = o * (size_t)extent * inner + i;
+        float h[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) h[t] = 0.0f;
+        for (int e = 0; e < extent; e++) {
+#pragma unroll
+            for (int t = 7; t > 0; t--) h[t] = h[t - 1];
+            h[0] = in[base + (size_t)e * inner];
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; t++) acc = fmaf(w.k[t], h[t], acc);
+            if (ACCUMULATE)
+                out[base + (size_t)e * inner] += acc;
+            else
+                out[base + (size_t)e * inner] = acc;
+        }
+    }
+}
+
+hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
+                                   const float* win1d, hipStream_t s) {
+    Win1D w;
+    for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
+    const size_t n = (size_t)nz * ny * nx * (size_t)batch;
+    auto blocks = [](size_t items) {
+        size_t b = (items + EW_THREADS - 1) / EW_THREADS;
+        if (b > 65536) b = 65536;
+        return dim3((unsigned)(b ? b : 1));
+    };
+    hipLaunchKernelGGL(conv8_x_kernel, blocks(n), dim3(EW_THREADS), 0, s, C, tmp, n, nx, w);
+    const size_t ylines = (size_t)batch * nz * nx, zlines = (size_t)batch * ny * nx;
+    hipLaunchKernelGGL(conv8_line_kernel<false>, blocks(ylines), dim3(EW_THREADS), 0, s, tmp, C, ylines,
+                       (size_t)nx, ny, w);
+    hipLaunchKernelGGL(conv8_line_kernel<true>, blocks(zlines), dim3(EW_THREADS), 0, s, C, den, zlines,
+                       (size_t)ny * nx, nz, w);
+    return hipGetLastError();
+}
+
 static inline unsigned ew_blocks(size_t n) {
     size_t b = (n + EW_THREADS - 1) / EW_THREADS;
     if (b > (size_t)EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;

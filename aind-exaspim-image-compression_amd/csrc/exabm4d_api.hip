@@ -19,6 +19,7 @@ struct exabm4d_ctx {
     bool own_stream = false;
     float dct[64];
     float win[512];
+    float win1d[8];            // the window's 1-D factor (fp32), for den = C (*) win
     float* win_dev = nullptr;
     float* tf_lut = nullptr;   // 65536-entry forward table for uint16 input (asinh)
     double win_beta = -1.0;
@@ -60,7 +61,7 @@ static double bessel_i0(double x) {
     }
     return sum;
 }
-static void make_tables(double beta, float* dct64, float* win512) {
+static void make_tables(double beta, float* dct64, float* win512, float* win1d = nullptr) {
     const double pi = 3.14159265358979323846;
     for (int u = 0; u < 8; u++)
         for (int n = 0; n < 8; n++) {
@@ -79,6 +80,8 @@ static void make_tables(double beta, float* dct64, float* win512) {
     for (int z = 0; z < 8; z++)
         for (int y = 0; y < 8; y++)
             for (int x = 0; x < 8; x++) win512[(z * 8 + y) * 8 + x] = (float)(k[z] * k[y] * k[x]);
+    if (win1d)
+        for (int n = 0; n < 8; n++) win1d[n] = (float)k[n];
 }
 
 static int check_params(exabm4d_ctx* ctx, const exabm4d_params* p) {
@@ -114,7 +117,7 @@ static uint32_t keymax_of(float sigma, float c_match) {
 }
 static int ensure_window(exabm4d_ctx* ctx, double beta) {
     if (ctx->win_dev && ctx->win_beta == beta) return EXABM4D_OK;
-    make_tables(beta, ctx->dct, ctx->win);
+    make_tables(beta, ctx->dct, ctx->win, ctx->win1d);
     if (!ctx->win_dev) HIP_TRY(ctx, hipMalloc((void**)&ctx->win_dev, sizeof(float) * 512));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(ctx->win_dev, ctx->win, sizeof(float) * 512, hipMemcpyHostToDevice));
@@ -352,8 +355,10 @@ size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages) {
     if (nz < 8 || ny < 8 || nx < 8 || batch < 1) return 0;
     const size_t n = (size_t)nz * ny * nx * (size_t)batch;
     const size_t nref = (size_t)grid_count(nz) * grid_count(ny) * grid_count(nx) * (size_t)batch;
+    // keys, num, den, [basic], and the two work volumes of the denominator convolution
     size_t b = align256(nref * MAXG * sizeof(uint32_t)) + 2 * align256(n * sizeof(float));
     if (stages >= 2) b += align256(n * sizeof(float));
+    b += align256(2 * n * sizeof(float));
     return b;
 }
 
@@ -412,8 +417,12 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
     if (rc) return rc;
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
+    const size_t n = (size_t)g.nvox * (size_t)batch;
+    rc = ensure_scratch(ctx, align256(2 * n * sizeof(float)));
+    if (rc) return rc;
     HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, num,
-                              den, ctx->stream, ctx->stage_pairs));
+                              den, ctx->stream, ctx->stage_pairs, ctx->win1d,
+                              static_cast<float*>(ctx->scratch)));
     return EXABM4D_OK;
 }
 
@@ -453,6 +462,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     float* den = reinterpret_cast<float*>(scratch);
     scratch += align256(n * sizeof(float));
     float* basic = reinterpret_cast<float*>(scratch);  // only touched when stages >= 2
+    if (stages >= 2) scratch += align256(n * sizeof(float));
+    float* cwork = reinterpret_cast<float*>(scratch);  // 2 n floats: corner weights + ping-pong
 
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
@@ -473,7 +484,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
         HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                  sigma2, num, den, s, ctx->stage_pairs));
+                                  sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork));
     }
     if (stages >= 2) {
         {
@@ -493,7 +504,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
             HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                      sigma2, num, den, s, ctx->stage_pairs));
+                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork));
         }
     }
     {

@@ -624,11 +624,20 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
 // combines only the two halves' approximation coefficients -- 8 values per lane -- which the
 // waves swap through their transpose buffers.  Every operation is the one the single-wave path
 // (and the oracle) performs, in the same order, so results are bit-identical up to the order of
-// the aggregation sums.  A 4x3 tile (ring 18 x 26 x 30) makes room for eight transpose buffers.
+// the aggregation sums.
+//
+// The ring holds the numerator only.  The denominator of the aggregation is a convolution:
+// den(v) = sum over blocks of w_b * win(v - corner_b) = (C (*) win)(v) with C(c) = sum of the
+// weights of the blocks whose corner is c, and win separable.  So a block costs ONE global atomic
+// (its weight onto its corner in C) instead of 512 ring updates for den, and the launcher turns C
+// into den with three 8-tap passes (launch_den_from_corners).  Half the ring (94 KB for 26 planes
+// of a 4x4 tile) leaves room for eight transpose buffers AND two extra layers of planes, so a
+// layer's blocks wait for the flush of layer - 3 instead of layer - 1.
 // =================================================================================================
-constexpr int HTY = 3;                        // grid points per tile in y (x keeps TILE_R = 4)
-constexpr int HROWS = (HTY - 1) * STEP + 18;  // 26 region rows
-constexpr int HPS = 808;                      // plane stride: 780 padded to 8 (mod 32)
+constexpr int HPS = PS;                        // 4x4 tiles like the one-wave kernels: 30 x 30 region
+constexpr int HNPL = 26;                      // ring planes: one layer's 18 plus two more layers' 4 + 4,
+                                              // so that a layer waits for the flush of layer - 3 only
+constexpr int HNCNT = 8;                      // per-layer report counters (at most 4 layers in flight)
 constexpr int HNW = 8;                        // waves: pair p = wave >> 1, half h = wave & 1 (the waves
                                               // of a pair sit on different SIMDs; the two waves of
                                               // a SIMD belong to different pairs and drift apart)
@@ -696,6 +705,22 @@ __device__ __forceinline__ void half_unshrink_local(f16v (&S)[4], const f2 (&app
     }
 }
 
+// Numerator-only ring of the two-waves-per-group kernels: move planes [zlo, zhi) to global memory
+// (float atomics: neighbouring tiles overlap) and zero them.  By ONE wave / by the whole workgroup.
+__device__ __forceinline__ void flush_num_plane(float* ring, float* __restrict__ num, int z,
+                                                const TileGeom& tg, const VolGeom& g, int lane) {
+    float* plane = ring + ((z + 5) % HNPL) * HPS;
+    for (int rem = lane; rem < REG * REG; rem += 64) {
+        const float v = plane[rem];
+        if (v != 0.0f) {
+            const int ryy = rem / REG, rxx = rem - ryy * REG;
+            // a non-zero sum implies a block covered this voxel, so it lies inside the volume
+            atomicAdd(num + ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx), v);
+            plane[rem] = 0.0f;
+        }
+    }
+}
+
 // Wiener counterparts.  Spectrum layout S[j][2 kl + c]: coefficient plane j of local block kl,
 // c = 0 noisy, c = 1 basic estimate, so the forward Haar transforms of both run as one packed
 // stream.  Local part: Haar over the half, Wiener-filter the detail coefficients (W = e / (e +
@@ -751,8 +776,8 @@ template <bool WIENER>
 __device__ __forceinline__ bool process_half_group(
     const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
     int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const DctTable& T,
-    const float (&win)[8], float thr, float sigma2, f2* ring, f2* tb, f2* partner_tb, int* lock,
-    int* sync, int wave, int& seq, int layer, int target, int lane
+    const float (&win)[8], float thr, float sigma2, float* ring, float* __restrict__ cvol, f2* tb,
+    f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
 #endif
@@ -950,16 +975,21 @@ __device__ __forceinline__ bool process_half_group(
         float ww[8];
 #pragma unroll
         for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+        // denominator: this half's blocks put their weight onto their corners (see above)
+        if (lane >= kb && lane < kb + KH) atomicAdd(cvol + (size_t)my_corner, w);
 
-        const int my_slot0 = (rz + my_dz + 5 + NPL) % NPL;
+        const int my_slot0 = (rz + my_dz + 5 + HNPL) % HNPL;
         const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
         // the partner must have read my approximations before the inverse transposes overwrite them
         STAMP(t2);
         STAMP_ADD(1, t1, t2);
         if (K > 1) wait_flag(sync + HNW + partner, seq, lane);
+        // Ring slots are re-used every HNPL = 26 planes: the planes this layer adds on top alias the
+        // ones layer - 3 retired, so lock[1] (layers retired so far, in order) must be >= layer - 2.
         if (lane == 0) {
-            while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
-                __builtin_amdgcn_s_sleep(12);
+            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                   layer - 2)
+                __builtin_amdgcn_s_sleep(8);
         }
         STAMP(t3);
         STAMP_ADD(5, t2, t3);
@@ -974,30 +1004,28 @@ __device__ __forceinline__ bool process_half_group(
             }
             pair_inv(T, tb, hi, lo, v2);
             int slot_a = __builtin_amdgcn_readlane(my_slot0, kb + kl) + hi;
-            slot_a -= slot_a >= NPL ? NPL : 0;
+            slot_a -= slot_a >= HNPL ? HNPL : 0;
             const int off_a = slot_a * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl) + lo;
             int slot_b = __builtin_amdgcn_readlane(my_slot0, kb + kl2) + hi;
-            slot_b -= slot_b >= NPL ? NPL : 0;
+            slot_b -= slot_b >= HNPL ? HNPL : 0;
             const int off_b = slot_b * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl2) + lo;
             STAMP(tl0);
             ring_lock_ticket(lock, lane);
             STAMP(tl1);
             STAMP_ADD(3, tl0, tl1);
             {
-                f2 acc[8];
+                float acc[8];
 #pragma unroll
                 for (int y = 0; y < 8; y++) acc[y] = ring[off_a + y * REG];
 #pragma unroll
-                for (int y = 0; y < 8; y++)
-                    ring[off_a + y * REG] = acc[y] + mk2(ww[y] * v2[y].x, ww[y]);
+                for (int y = 0; y < 8; y++) ring[off_a + y * REG] = acc[y] + ww[y] * v2[y].x;
             }
             if (kl2 != kl) {
-                f2 acc[8];
+                float acc[8];
 #pragma unroll
                 for (int y = 0; y < 8; y++) acc[y] = ring[off_b + y * REG];
 #pragma unroll
-                for (int y = 0; y < 8; y++)
-                    ring[off_b + y * REG] = acc[y] + mk2(ww[y] * v2[y].y, ww[y]);
+                for (int y = 0; y < 8; y++) ring[off_b + y * REG] = acc[y] + ww[y] * v2[y].y;
             }
             ring_unlock_ticket(lock, lane);
             STAMP(tl2);
@@ -1005,17 +1033,20 @@ __device__ __forceinline__ bool process_half_group(
         }
     }
     if (!active) {
-        // An idle half still reports, but like everybody else only once the previous layer is
-        // closed: reports of layer L+1 must never be counted towards layer L.
+        // An idle half (one-block group) still reports, and like everybody else only once layer - 3
+        // has been retired: at most four layers are in flight, the report counters have eight slots.
         if (lane == 0) {
-            while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
-                __builtin_amdgcn_s_sleep(12);
+            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
+                   layer - 2)
+                __builtin_amdgcn_s_sleep(8);
         }
         cbar();
     }
-    // every wave of the pair reports once per group; all lanes take part in the atomic (a
-    // lane-0-only fetch in front of wave-wide code has been miscompiled before)
-    closer = (__hip_atomic_fetch_add(lock + 1, lane == 0 ? 1 : 0, __ATOMIC_RELAXED,
+    // Every wave of the pair reports once per group, into the counter of the group's layer (waves
+    // run up to two layers ahead, whose reports must not be mistaken for this layer's).  All lanes
+    // take part in the atomic (a lane-0-only fetch in front of wave-wide code has been miscompiled
+    // before).
+    closer = (__hip_atomic_fetch_add(cnt + (layer & (HNCNT - 1)), lane == 0 ? 1 : 0, __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == target) ? 1 : 0;
     return __builtin_amdgcn_readfirstlane(closer) != 0;
 }
@@ -1024,30 +1055,31 @@ template <bool WIENER>
 __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
     const uint32_t* __restrict__ keys_all, VolGeom g, DctTable T, const float* __restrict__ win_g,
-    float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ den_all, int tiles_x,
+    float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x,
     int layers_per_chunk) {
     extern __shared__ __align__(16) float lds[];
-    f2* ring = reinterpret_cast<f2*>(lds);                 // [NPL][HPS] (num, den) pairs
+    float* ring = lds;                                     // [HNPL][HPS] numerator sums
     // readfirstlane: the wave index steers register indexing below and must be provably uniform
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    f2* tb = reinterpret_cast<f2*>(lds + 2 * NPL * HPS + wave * 2 * TBUF);
-    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * NPL * HPS + (wave ^ 1) * 2 * TBUF);
-    int* lock = reinterpret_cast<int*>(lds + 2 * NPL * HPS + HNW * 2 * TBUF);
+    f2* tb = reinterpret_cast<f2*>(lds + HNPL * HPS + wave * 2 * TBUF);
+    f2* partner_tb = reinterpret_cast<f2*>(lds + HNPL * HPS + (wave ^ 1) * 2 * TBUF);
+    int* lock = reinterpret_cast<int*>(lds + HNPL * HPS + HNW * 2 * TBUF);
     int* sync = lock + 4;                                  // ready[HNW], ack[HNW]
+    int* cnt = sync + 2 * HNW;                             // reports per layer (slot = layer & 7)
 
     const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
     const float* __restrict__ noisy = noisy_all + voff;
     const float* __restrict__ basic = WIENER ? basic_all + voff : nullptr;
     float* __restrict__ num = num_all + voff;
-    float* __restrict__ den = den_all + voff;
+    float* __restrict__ cvol = cvol_all + voff;
     const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int iy0 = HTY * ty, ix0 = TILE_R * tx;
+    const int iy0 = TILE_R * ty, ix0 = TILE_R * tx;
     TileGeom tg;
-    tg.nry = min(HTY, g.gy - iy0);
+    tg.nry = min(TILE_R, g.gy - iy0);
     tg.nrx = min(TILE_R, g.gx - ix0);
     tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
     tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
@@ -1056,8 +1088,9 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     const int izb = blockIdx.y * layers_per_chunk;
     const int ize = min(g.gz, izb + layers_per_chunk);
 
-    for (int i = threadIdx.x; i < 2 * NPL * HPS; i += HNW * 64) lds[i] = 0.0f;
-    if (threadIdx.x < 4 + 2 * HNW) lock[threadIdx.x] = threadIdx.x == 2 ? 1 : 0;
+    for (int i = threadIdx.x; i < HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;
+    // lock[0] = ticket being served, lock[1] = layers retired (in order), lock[3] = next ticket
+    if (threadIdx.x < 4 + 2 * HNW + HNCNT) lock[threadIdx.x] = 0;
 
     float win[8];
     {
@@ -1082,31 +1115,38 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
             const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
             const bool closer = process_half_group<WIENER>(
-                noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2, ring, tb, partner_tb,
-                lock, sync, wave, seq, layer, 2 * nrefs * (layer + 1), lane
+                noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2, ring, cvol, tb,
+                partner_tb, lock, sync, cnt, wave, seq, layer, 2 * nrefs, lane
 #ifdef EXABM4D_STAMPS
                 , st
 #endif
             );
             if (closer) {
-                STAMP(tf0);
+                // this layer's counter slot is next used eight layers on
+                if (lane == 0)
+                    __hip_atomic_store(cnt + (layer & (HNCNT - 1)), 0, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (iz + 1 < ize) {
                     const int zn = grid_pos(iz + 1, g.az, g.nz);
-                    flush_planes_wave<HROWS, HPS>(ring, num, den, z0 - RAD, zn - RAD, tg, g, lane);
+                    for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane(ring, num, z, tg, g, lane);
                 }
                 cbar();
-                if (lane == 0)
-                    __hip_atomic_store(lock + 2, layer + 2, __ATOMIC_RELAXED,
+                // layers retire in order: wait for the previous layer's flush, then count this one
+                if (lane == 0) {
+                    while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP) != layer)
+                        __builtin_amdgcn_s_sleep(2);
+                    __hip_atomic_store(lock + 1, layer + 1, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                STAMP(tf1);
-                STAMP_ADD(6, tf0, tf1);
+                }
+                cbar();
             }
         }
     }
     __syncthreads();
     if (ize > izb) {
         const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
-        flush_planes<HROWS, HPS>(ring, num, den, base, base + NPL, tg, g, HNW);
+        for (int z = base + wave; z < base + HNPL; z += HNW) flush_num_plane(ring, num, z, tg, g, lane);
     }
 #ifdef EXABM4D_STAMPS
     st[7] = stamp() - tk0;
@@ -1121,7 +1161,7 @@ constexpr int NW_WIE = 4;
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs) {
+                        int wave_pairs, const float* win1d, float* cwork) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
     const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
@@ -1134,28 +1174,29 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
     chunks = (g.gz + lpc - 1) / lpc;
     dim3 grid((unsigned)(tiles_y * tiles_x), (unsigned)chunks, (unsigned)batch);
     if (wave_pairs) {
-        const int hty = (g.gy + HTY - 1) / HTY;
-        const long long htiles = (long long)hty * tiles_x * batch;
-        int hchunks = (int)((1024 + htiles - 1) / htiles);
-        if (hchunks < 1) hchunks = 1;
-        if (hchunks > g.gz) hchunks = g.gz;
-        const int hlpc = (g.gz + hchunks - 1) / hchunks;
-        hchunks = (g.gz + hlpc - 1) / hlpc;
-        const size_t lds = sizeof(float) * (2 * NPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW);
-        const dim3 hgrid((unsigned)(hty * tiles_x), (unsigned)hchunks, (unsigned)batch);
+        // The two-waves-per-group kernels collect the numerator in `num` and the weight of every
+        // block on its corner voxel in cwork[0 .. n); den += C (*) win follows in three 8-tap passes
+        // (cwork[n .. 2n) is the ping-pong buffer).
+        const size_t n = (size_t)g.nvox * (size_t)batch;
+        hipError_t e = hipMemsetAsync(cwork, 0, n * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+        const size_t lds = sizeof(float) * (HNPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW + HNCNT);
         if (basic) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(stage_half_kernel<true>, hgrid, dim3(HNW * 64), lds, stream, noisy, basic,
-                               keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, hlpc);
+            hipLaunchKernelGGL(stage_half_kernel<true>, grid, dim3(HNW * 64), lds, stream, noisy, basic,
+                               keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, lpc);
         } else {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(stage_half_kernel<false>, hgrid, dim3(HNW * 64), lds, stream, noisy,
-                               basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, hlpc);
+            hipLaunchKernelGGL(stage_half_kernel<false>, grid, dim3(HNW * 64), lds, stream, noisy,
+                               basic, keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, lpc);
         }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d, stream);
     } else if (basic) {
         const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * 2 * TBUF + 4);
         hipError_t e = hipFuncSetAttribute(
