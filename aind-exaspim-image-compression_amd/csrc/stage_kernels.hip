@@ -237,15 +237,20 @@ __device__ __forceinline__ void ring_lock_ticket(int* lock, int lane) {
     if (lane == 0) {
         const int ticket = __hip_atomic_fetch_add(lock + 3, 1, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        // long naps: the holder's s_wakeup ends them the moment the lock changes hands
         while (__hip_atomic_load(lock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
-            __builtin_amdgcn_s_sleep(3);
+            __builtin_amdgcn_s_sleep(16);
     }
     cbar();
 }
 __device__ __forceinline__ void ring_unlock_ticket(int* lock, int lane) {
     cbar();
-    if (lane == 0)
+    if (lane == 0) {
         __hip_atomic_fetch_add(lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // wake every wave of the workgroup that sleeps in a wait loop (s_sleep): the next ticket
+        // holder re-reads the lock at once instead of at the end of its sleep quantum
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+    }
     cbar();
 }
 __device__ __forceinline__ void ring_unlock(int* lock, int lane) {
