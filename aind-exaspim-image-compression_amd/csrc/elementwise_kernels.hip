@@ -330,24 +330,12 @@ hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz
 struct Win1D {
     float k[8];
 };
-// along x: one thread per output voxel, its 8 inputs are neighbours in a row (L1 hits)
-__global__ __launch_bounds__(EW_THREADS) void conv8_x_kernel(const float* __restrict__ in,
-                                                             float* __restrict__ out, size_t n, int nx,
-                                                             Win1D w) {
-    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * EW_THREADS) {
-        const int x = (int)(i % (size_t)nx);
-        float acc = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 8; t++)
-            if (t <= x) acc = fmaf(w.k[t], in[i - t], acc);
-        out[i] = acc;
-    }
-}
 // along y or z: one thread per line (lanes along x: coalesced), marching with the last 8 inputs
 // in registers, so every input is read once.  Line (o, i): base = o * extent * inner + i,
 // element stride `inner`.
-template <bool ACCUMULATE>
+// With XFIRST the value fed into the line is itself the 8-tap convolution along x of the input
+// row (8 neighbouring loads, L1 hits), which fuses the x and y passes.
+template <bool ACCUMULATE, bool XFIRST>
 __global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __restrict__ in,
                                                                 float* __restrict__ out, size_t nlines,
                                                                 size_t inner, int extent, Win1D w) {
@@ -361,7 +349,17 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __r
         for (int e = 0; e < extent; e++) {
 #pragma unroll
             for (int t = 7; t > 0; t--) h[t] = h[t - 1];
-            h[0] = in[base + (size_t)e * inner];
+            if (XFIRST) {
+                // lines run along y, `inner` is the row length and i the x coordinate
+                const float* row = in + base + (size_t)e * inner;
+                float ax = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    if ((size_t)t <= i) ax = fmaf(w.k[t], *(row - t), ax);
+                h[0] = ax;
+            } else {
+                h[0] = in[base + (size_t)e * inner];
+            }
             float acc = 0.0f;
 #pragma unroll
             for (int t = 0; t < 8; t++) acc = fmaf(w.k[t], h[t], acc);
@@ -377,18 +375,17 @@ hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int
                                    const float* win1d, hipStream_t s) {
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
-    const size_t n = (size_t)nz * ny * nx * (size_t)batch;
     auto blocks = [](size_t items) {
         size_t b = (items + EW_THREADS - 1) / EW_THREADS;
         if (b > 65536) b = 65536;
         return dim3((unsigned)(b ? b : 1));
     };
-    hipLaunchKernelGGL(conv8_x_kernel, blocks(n), dim3(EW_THREADS), 0, s, C, tmp, n, nx, w);
+    // x and y fused (C -> tmp), then z (den += conv(tmp))
     const size_t ylines = (size_t)batch * nz * nx, zlines = (size_t)batch * ny * nx;
-    hipLaunchKernelGGL(conv8_line_kernel<false>, blocks(ylines), dim3(EW_THREADS), 0, s, tmp, C, ylines,
-                       (size_t)nx, ny, w);
-    hipLaunchKernelGGL(conv8_line_kernel<true>, blocks(zlines), dim3(EW_THREADS), 0, s, C, den, zlines,
-                       (size_t)ny * nx, nz, w);
+    hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp,
+                       ylines, (size_t)nx, ny, w);
+    hipLaunchKernelGGL((conv8_line_kernel<true, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp, den,
+                       zlines, (size_t)ny * nx, nz, w);
     return hipGetLastError();
 }
 

@@ -62,8 +62,8 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
                         int wave_pairs, const float* win1d, float* cwork);
-// den += C (*) win for the separable window win = k (x) k (x) k: x pass C -> tmp, y pass tmp -> C,
-// z pass den += conv(C).  C is overwritten.
+// den += C (*) win for the separable window win = k (x) k (x) k: fused x / y pass C -> tmp, z pass
+// den += conv(tmp).
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
                                    const float* win1d, hipStream_t s);
 
