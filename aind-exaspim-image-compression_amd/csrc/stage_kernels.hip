@@ -701,13 +701,20 @@ __device__ __forceinline__ void half_unshrink_local(f16v (&S)[4], const f2 (&app
 __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict__ num, int z,
                                                 const TileGeom& tg, const VolGeom& g, int lane) {
     ring_t* plane = ring + ((z + 5) % HNPL) * HPS;
-    for (int rem = lane; rem < HROWS * REG; rem += 64) {
-        const ring_t v = plane[rem];
-        if (v != 0.0) {
-            const int ryy = rem / REG, rxx = rem - ryy * REG;
-            // a non-zero sum implies a block covered this voxel, so it lies inside the volume
-            atomicAdd(num + ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx), (float)v);
-            plane[rem] = 0.0;
+    constexpr int N = HROWS * REG, U = 4;     // four LDS reads in flight per lane
+    for (int rem0 = lane; rem0 < N; rem0 += 64 * U) {
+        ring_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = (rem0 + 64 * u < N) ? plane[rem0 + 64 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int rem = rem0 + 64 * u;
+            if (v[u] != 0.0) {
+                const int ryy = rem / REG, rxx = rem - ryy * REG;
+                // a non-zero sum implies a block covered this voxel, so it lies inside the volume
+                atomicAdd(num + ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx), (float)v[u]);
+                plane[rem] = 0.0;
+            }
         }
     }
 }
