@@ -211,12 +211,19 @@ def main():
 
     dist = None
     torch = None
+    # BENCH_REHEARSAL=1: rehearse the multi-rank control flow on a box with ONE GPU -- gloo
+    # rendezvous, every rank on device 0 (never the measured configuration).
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from aind_exaspim_image_compression import _native
 
@@ -254,7 +261,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if rehearsal else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
