@@ -372,7 +372,7 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __r
 }
 
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
-                                   const float* win1d, hipStream_t s) {
+                                   const float* win1d, int overwrite, hipStream_t s) {
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
     auto blocks = [](size_t items) {
@@ -384,8 +384,12 @@ hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int
     const size_t ylines = (size_t)batch * nz * nx, zlines = (size_t)batch * ny * nx;
     hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp,
                        ylines, (size_t)nx, ny, w);
-    hipLaunchKernelGGL((conv8_line_kernel<true, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp, den,
-                       zlines, (size_t)ny * nx, nz, w);
+    if (overwrite)
+        hipLaunchKernelGGL((conv8_line_kernel<false, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp,
+                           den, zlines, (size_t)ny * nx, nz, w);
+    else
+        hipLaunchKernelGGL((conv8_line_kernel<true, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp,
+                           den, zlines, (size_t)ny * nx, nz, w);
     return hipGetLastError();
 }
 

@@ -422,7 +422,7 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
     if (rc) return rc;
     HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, num,
                               den, ctx->stream, ctx->stage_pairs, ctx->win1d,
-                              static_cast<float*>(ctx->scratch)));
+                              static_cast<float*>(ctx->scratch), 0));
     return EXABM4D_OK;
 }
 
@@ -474,7 +474,9 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_1);
         HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
-        HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+        // the two-waves-per-group path writes den (convolution of the corner weights) instead of
+        // adding into it
+        if (!ctx->stage_pairs) HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);
@@ -484,7 +486,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
         HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                  sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork));
+                                  sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork,
+                                  ctx->stage_pairs));
     }
     if (stages >= 2) {
         {
@@ -494,7 +497,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_2);
             HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
-            HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+            if (!ctx->stage_pairs) HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
@@ -504,7 +507,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
             HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork));
+                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork,
+                                  ctx->stage_pairs));
         }
     }
     {

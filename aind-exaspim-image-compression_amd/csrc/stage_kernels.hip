@@ -1154,7 +1154,7 @@ constexpr int NW_WIE = 4;
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs, const float* win1d, float* cwork) {
+                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
     const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
@@ -1197,7 +1197,8 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d, stream);
+        return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d,
+                                       den_overwrite, stream);
     } else if (basic) {
         const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * 2 * TBUF + 4);
         hipError_t e = hipFuncSetAttribute(
