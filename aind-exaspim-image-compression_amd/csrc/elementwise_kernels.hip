@@ -371,6 +371,54 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __r
     }
 }
 
+// Fused x / y pass for row lengths that are multiples of 4: one thread owns four consecutive x
+// outputs and marches along y.  Per row it loads its own float4 and the eight values to its left
+// (three 16-byte loads for four outputs instead of eight scalar loads per output), forms the four
+// x-convolutions in registers and pushes them through four 8-deep y shift registers.
+__global__ __launch_bounds__(EW_THREADS) void conv8_xy4_kernel(const float* __restrict__ in,
+                                                               float* __restrict__ out, size_t nlines,
+                                                               int nx4, int ny, Win1D w) {
+    for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
+         l += (size_t)gridDim.x * EW_THREADS) {
+        const size_t o = l / (size_t)nx4;              // (volume, z) index
+        const int x0 = 4 * (int)(l - o * (size_t)nx4);
+        const size_t nx = 4 * (size_t)nx4;
+        const size_t base = o * (size_t)ny * nx + (size_t)x0;
+        float h[8][4];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) h[t][j] = 0.0f;
+        for (int y = 0; y < ny; y++) {
+            const float* row = in + base + (size_t)y * nx;
+            const float4 c = *reinterpret_cast<const float4*>(row);
+            const float4 l1 = x0 >= 4 ? *reinterpret_cast<const float4*>(row - 4) : make_float4(0, 0, 0, 0);
+            const float4 l2 = x0 >= 8 ? *reinterpret_cast<const float4*>(row - 8) : make_float4(0, 0, 0, 0);
+            const float win_[12] = {l2.x, l2.y, l2.z, l2.w, l1.x, l1.y, l1.z, l1.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int t = 7; t > 0; t--)
+#pragma unroll
+                for (int j = 0; j < 4; j++) h[t][j] = h[t - 1][j];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float ax = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 8; t++) ax = fmaf(w.k[t], win_[8 + j - t], ax);
+                h[0][j] = ax;
+            }
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 8; t++) acc = fmaf(w.k[t], h[t][j], acc);
+                r[j] = acc;
+            }
+            *reinterpret_cast<float4*>(out + base + (size_t)y * nx) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
                                    const float* win1d, int overwrite, hipStream_t s) {
     Win1D w;
@@ -382,8 +430,14 @@ hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int
     };
     // x and y fused (C -> tmp), then z (den += conv(tmp))
     const size_t ylines = (size_t)batch * nz * nx, zlines = (size_t)batch * ny * nx;
-    hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp,
-                       ylines, (size_t)nx, ny, w);
+    if (nx % 4 == 0 && ((uintptr_t)C & 15u) == 0 && ((uintptr_t)tmp & 15u) == 0) {
+        const size_t lines4 = (size_t)batch * nz * (nx / 4);
+        hipLaunchKernelGGL(conv8_xy4_kernel, blocks(lines4), dim3(EW_THREADS), 0, s, C, tmp, lines4, nx / 4,
+                           ny, w);
+    } else {
+        hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp,
+                           ylines, (size_t)nx, ny, w);
+    }
     if (overwrite)
         hipLaunchKernelGGL((conv8_line_kernel<false, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp,
                            den, zlines, (size_t)ny * nx, nz, w);
