@@ -180,6 +180,18 @@ def test_pipeline_u16(ctx, oracle):
     assert np.mean(d > 0) < 2e-3
 
 
+@pytest.mark.parametrize("shape", [(8, 8, 8), (8, 9, 12), (12, 8, 8), (9, 9, 9), (16, 8, 20),
+                                   (8, 64, 8), (13, 11, 10)])
+def test_tiny_and_thin_volumes_full_pipeline(ctx, oracle, shape):
+    """One reference block per axis, one-tile volumes, clamped grid points on every axis: most
+    wave pairs of a workgroup have nothing to do, the rest must still synchronise correctly."""
+    vol = synth_volume(shape, seed=sum(shape))[0]
+    for stages in (1, 2):
+        want = oracle.bm4d(vol, SIGMA, stages=stages)
+        got = ctx.denoise_f32_host(vol, SIGMA, stages=stages)
+        assert np.abs(got - want).max() < 0.05
+
+
 def test_bad_arguments_raise(ctx):
     from aind_exaspim_image_compression import _native as nat
     with pytest.raises(ValueError):
