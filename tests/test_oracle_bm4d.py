@@ -117,3 +117,35 @@ def test_dct_quantiser_oracle_properties(oracle):
     assert one.shape == (1, 1, 1, 512) and np.count_nonzero(one[0, 0, 0, 1:]) == 0
     coarse = oracle.dctq_inverse(oracle.dctq_forward(vol, 32.0), vol.shape, 32.0)
     assert 1.0 < np.abs(coarse.astype(np.float64) - vol).mean() < 32.0
+
+
+def test_aggregation_denominator_is_a_convolution(oracle):
+    """The identity behind the device path: den(v) = sum_b w_b win(v - c_b) equals
+    the corner-weight volume C convolved with the separable window, here with the oracle's own
+    window table and three causal 8-tap passes in float32."""
+    rng = np.random.default_rng(5)
+    shape = (24, 28, 33)
+    _, win = oracle.tables()
+    win = np.asarray(win, dtype=np.float32).reshape(8, 8, 8)
+    k = (win[:, 0, 0] / win[0, 0, 0]).astype(np.float64)          # 1-D factor, k[0] = win[0,0,0]^(1/3)
+    k *= float(win[0, 0, 0]) ** (1.0 / 3.0)
+    np.testing.assert_allclose(np.einsum("i,j,k->ijk", k, k, k), win, rtol=2e-6)
+    den = np.zeros(shape, np.float64)
+    C = np.zeros(shape, np.float32)
+    for _ in range(300):
+        c = [int(rng.integers(0, n - 7)) for n in shape]
+        w = np.float32(rng.uniform(1e-6, 1e-3))
+        den[c[0]:c[0] + 8, c[1]:c[1] + 8, c[2]:c[2] + 8] += np.float64(w) * win
+        C[c[0], c[1], c[2]] += w
+    k32 = k.astype(np.float32)
+    out = C.copy()
+    for axis in (2, 1, 0):                                        # x, y, z: out(i) = sum_t k[t] in(i - t)
+        acc = np.zeros_like(out)
+        for t in range(8):
+            sl_dst = [slice(None)] * 3
+            sl_src = [slice(None)] * 3
+            sl_dst[axis] = slice(t, None)
+            sl_src[axis] = slice(0, out.shape[axis] - t)
+            acc[tuple(sl_dst)] += k32[t] * out[tuple(sl_src)]
+        out = acc
+    np.testing.assert_allclose(out, den, rtol=2e-5, atol=1e-12)
