@@ -68,6 +68,75 @@ __device__ __forceinline__ void dct8_inv2(const DctTable& T, f2 (&v)[8]) {
     for (int n = 0; n < 8; n++) v[n] = x[n];
 }
 
+// ---- the same 8-point transforms on the matrix pipe ------------------------------------------------
+// v_mfma_f32_4x4x1_16b_f32 does 16 independent 4x4 outer products: lane l = 4 b + r supplies
+// A_b[r] and B_b[r], register i of lane l accumulates D_b[i][r] += A_b[i] * B_b[r] with ONE fp32
+// fma (CDNA4 f32-input MFMA is bit-for-bit a k-ordered fmaf chain).  With A = row (l & 3) of a 4x4
+// coefficient block and B = the lane's own folded sample, four chained instructions leave the
+// four even (or odd) outputs of the lane's OWN line in the lane's registers: the chain
+// c0*s0 -> fma(c1,s1,.) -> fma(c2,s2,.) -> fma(c3,s3,.) of chain4p, no data movement, and the
+// VALU only does the fold / unfold additions.  (fma(c0, s0, +0) instead of the product c0 * s0
+// differs only in the sign of an exact zero.)
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct DctLane {
+    float fe[4], fo[4], ie[4], io[4];   // per-lane A operands: forward even / odd, inverse even / odd
+};
+__device__ __forceinline__ DctLane make_dct_lane(const DctTable& T, int lane) {
+    DctLane L;
+    const int i = lane & 3;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        // selects instead of a lane-indexed read: T lives in scalar registers / kernel arguments
+        auto pick = [&](float a, float b, float c, float d) {
+            return i == 0 ? a : i == 1 ? b : i == 2 ? c : d;
+        };
+        L.fe[k] = pick(T.d[0 * 8 + k], T.d[2 * 8 + k], T.d[4 * 8 + k], T.d[6 * 8 + k]);
+        L.fo[k] = pick(T.d[1 * 8 + k], T.d[3 * 8 + k], T.d[5 * 8 + k], T.d[7 * 8 + k]);
+        L.ie[k] = pick(T.d[(2 * k) * 8 + 0], T.d[(2 * k) * 8 + 1], T.d[(2 * k) * 8 + 2],
+                       T.d[(2 * k) * 8 + 3]);
+        L.io[k] = pick(T.d[(2 * k + 1) * 8 + 0], T.d[(2 * k + 1) * 8 + 1], T.d[(2 * k + 1) * 8 + 2],
+                       T.d[(2 * k + 1) * 8 + 3]);
+    }
+    return L;
+}
+__device__ __forceinline__ void dct8_fwd2(const DctLane& L, f2 (&v)[8]) {
+    f2 s[4], d[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s[n] = v[n] + v[7 - n];
+        d[n] = v[n] - v[7 - n];
+    }
+    f4v ex = (f4v)(0.0f), ox = (f4v)(0.0f), ey = (f4v)(0.0f), oy = (f4v)(0.0f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ex = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fe[k], s[k].x, ex, 0, 0, 0);
+        ox = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fo[k], d[k].x, ox, 0, 0, 0);
+        ey = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fe[k], s[k].y, ey, 0, 0, 0);
+        oy = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fo[k], d[k].y, oy, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        v[2 * i] = mk2(ex[i], ey[i]);
+        v[2 * i + 1] = mk2(ox[i], oy[i]);
+    }
+}
+__device__ __forceinline__ void dct8_inv2(const DctLane& L, f2 (&v)[8]) {
+    f4v ex = (f4v)(0.0f), ox = (f4v)(0.0f), ey = (f4v)(0.0f), oy = (f4v)(0.0f);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ex = __builtin_amdgcn_mfma_f32_4x4x1f32(L.ie[k], v[2 * k].x, ex, 0, 0, 0);
+        ox = __builtin_amdgcn_mfma_f32_4x4x1f32(L.io[k], v[2 * k + 1].x, ox, 0, 0, 0);
+        ey = __builtin_amdgcn_mfma_f32_4x4x1f32(L.ie[k], v[2 * k].y, ey, 0, 0, 0);
+        oy = __builtin_amdgcn_mfma_f32_4x4x1f32(L.io[k], v[2 * k + 1].y, oy, 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const f2 e = mk2(ex[n], ey[n]), o = mk2(ox[n], oy[n]);
+        v[n] = e + o;
+        v[7 - n] = e - o;
+    }
+}
+
 // The transpose buffer is private to one wave and LDS executes a wave's instructions in issue
 // order, so between its writes and its (cross-lane) reads only the COMPILER must be kept from
 // reordering; no s_waitcnt or barrier is needed.
@@ -86,7 +155,8 @@ __device__ __forceinline__ void load8p(const f2* p, f2 (&v)[8]) {
 
 // 3-D DCT of TWO blocks at once (streams .x / .y; the transpose buffer holds float2 elements).
 // In: layout L1, out: L3.
-__device__ __forceinline__ void pair_fwd(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
+template <typename TableT>
+__device__ __forceinline__ void pair_fwd(const TableT& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_fwd2(T, v);                                             // along y
 #pragma unroll
     for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = v[y];  // buffer [z][y][x]
@@ -103,7 +173,8 @@ __device__ __forceinline__ void pair_fwd(const DctTable& T, f2* tb, int hi, int 
 }
 
 // Inverse of pair_fwd: L3 spectra in, spatial blocks in layout L1 out.
-__device__ __forceinline__ void pair_inv(const DctTable& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
+template <typename TableT>
+__device__ __forceinline__ void pair_inv(const TableT& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_inv2(T, v);                                             // along z (L3: hi = x, lo = y)
 #pragma unroll
     for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = v[z];  // buffer [z][y][x]

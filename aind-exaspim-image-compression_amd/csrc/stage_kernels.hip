@@ -620,6 +620,16 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
 // fires the 16 atomics of a block pair and moves on.  fp64 sums are also more accurate than the
 // fp32 read-modify-writes they replace.  18 planes of a 4x3 tile are 116 KB.
 // =================================================================================================
+#ifndef EXABM4D_MFMA_DCT
+#define EXABM4D_MFMA_DCT 0                     // 0: VALU chains (default: faster), 1: hard-threshold kernel on MFMA, 2: both kernels
+#endif
+template <bool M>
+__device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLane& L) {
+    if constexpr (M)
+        return L;
+    else
+        return T;
+}
 constexpr int HTY = 3;                         // grid points per tile in y (x keeps TILE_R = 4)
 constexpr int HROWS = (HTY - 1) * STEP + 18;  // 26 region rows
 constexpr int HPS = 808;                      // plane stride in elements: 780 padded to 8 (mod 32)
@@ -770,10 +780,10 @@ __device__ __forceinline__ void wiener_half_unlocal(f16v (&S)[8], const float (&
 // One wave, one half of a group.  `sync` = int[2 * HNW]: ready[w], ack[w]; `seq` = exchanges this
 // pair has done so far (both waves of a pair count alike).  Returns true for the wave that
 // completes the layer.
-template <bool WIENER>
+template <bool WIENER, typename TableT>
 __device__ __forceinline__ bool process_half_group(
     const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
-    int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const DctTable& T,
+    int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
     const float (&win)[8], float thr, float sigma2, ring_t* ring, float* __restrict__ cvol, f2* tb,
     f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane
 #ifdef EXABM4D_STAMPS
@@ -1095,6 +1105,10 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 
     const int pairid = wave >> 1;
     int seq = 0;
+    // 8-point transforms on the matrix pipe (dct_pairs.h) where the registers allow it
+    constexpr bool ON_MFMA = WIENER ? (EXABM4D_MFMA_DCT >= 2) : (EXABM4D_MFMA_DCT >= 1);
+    const DctLane TL = ON_MFMA ? make_dct_lane(T, lane) : DctLane{};
+    const auto& tab = pick_table<ON_MFMA>(T, TL);
 #ifdef EXABM4D_STAMPS
     unsigned long long st[16] = {};
     const unsigned long long tk0 = stamp();
@@ -1108,7 +1122,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
             const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
             const bool closer = process_half_group<WIENER>(
-                noisy, basic, kk, z0, ry, rx, tg, sy, sz, T, win, thr, sigma2, ring, cvol, tb,
+                noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, thr, sigma2, ring, cvol, tb,
                 partner_tb, lock, sync, cnt, wave, seq, layer, 2 * nrefs, lane
 #ifdef EXABM4D_STAMPS
                 , st
