@@ -38,6 +38,19 @@ def _model_device(model):
     return dev
 
 
+def tune_model(model):
+    """Opt-in MIOpen tuning for the BM4DNet stage on MI355X: NDHWC weights + exhaustive solver
+    search (``torch.backends.cudnn.benchmark``, process-wide).  U-Net forward, 32 x 64^3 fp32:
+    116 -> 69 ms (tools/dbg/unet_variants.py); same fp32 arithmetic, results differ by summation
+    order only (4e-6).  Both halves are needed -- NDHWC weights WITHOUT the search fall on a slow
+    default solver -- and the search runs once per input shape, so this is for long jobs; it is
+    not applied by default and ``predict`` itself never changes the caller's model."""
+    torch.backends.cudnn.benchmark = True
+    if isinstance(model, torch.nn.Module):
+        model.to(memory_format=torch.channels_last_3d)
+    return model
+
+
 def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, trim=5,
             verbose=True):
     """Denoise a 3-D image by overlapping-patch inference; returns uint16 counts.
@@ -81,8 +94,13 @@ def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, tri
             chunk = np.asarray(starts[b0:b0 + batch_size], dtype=np.int32)
             nb = len(chunk)
             ctx.tile_gather(vol, shape, chunk, patch_size, batch)      # inference.py:153-168
+            # A short last batch is run at full size (rows beyond nb hold the previous batch's
+            # patches and are dropped): MIOpen then sees ONE input shape per volume instead of
+            # paying a solver search -- seconds -- for the tail's.  Only for modules in eval mode,
+            # whose output rows do not depend on the rest of the batch.
+            full = nb < batch_size and b0 > 0 and not getattr(model, "training", True)
             with torch.no_grad():
-                out = model(batch[:nb])                                # inference.py:171-173
+                out = model(batch if full else batch[:nb])[:nb]        # inference.py:171-173
             out = out.to(torch.float32).contiguous()
             ctx.tile_accumulate(out, chunk, patch_size, trim, accum_pred, accum_wgt, shape)
             if pbar is not None:

@@ -48,6 +48,29 @@ def test_predict_matches_oracle_and_reference(case, model):
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3                # reference: SVML sinh, DESIGN 4.2
 
 
+def test_short_tail_batch_runs_at_full_size_in_eval_mode():
+    """Six patches in batches of four: in eval mode the tail of two goes through the model as a
+    full batch (one input shape for MIOpen); the result is the oracle's either way."""
+    shape = (130, 97, 64)
+    vol = tiling_volume(shape)
+    seen = []
+
+    class Recording(Affine):
+        def forward(self, x):
+            seen.append(x.shape[0])
+            return super().forward(x)
+
+    want = H.predict(vol, lambda b: b * np.float32(0.5) + np.float32(0.125),
+                     H.TransformOracle(TF_CFG), batch_size=4)
+    for mode, sizes in (("eval", [4, 4]), ("train", [4, 2])):
+        seen.clear()
+        net = Recording().cuda()
+        net = net.eval() if mode == "eval" else net.train()
+        got = inference.predict(vol, net, T.build_transform(TF_CFG), batch_size=4, verbose=False)
+        assert seen == sizes
+        np.testing.assert_array_equal(got, want)
+
+
 def test_tile_kernels_directly(ctx):
     rng = np.random.default_rng(1)
     shape = (40, 37, 45)

@@ -47,3 +47,14 @@ t0 = time.perf_counter()
 inference.predict(vol, ident, tf, batch_size=32, verbose=False)
 dt = time.perf_counter() - t0
 print(f"predict(256^3) stitching alone (identity model): {dt*1e3:.1f} ms", flush=True)
+
+# opt-in MIOpen tuning (inference.tune_model): search cost and steady state
+t0 = time.perf_counter()
+inference.tune_model(model)
+inference.predict(vol, model, tf, batch_size=32, verbose=False)
+first = time.perf_counter() - t0
+t0 = time.perf_counter()
+inference.predict(vol, model, tf, batch_size=32, verbose=False)
+dt = time.perf_counter() - t0
+print(f"tune_model: first predict(256^3) {first:.1f} s (solver search), then {dt:.2f} s = "
+      f"{vol.size/dt:.3e} voxels/s", flush=True)
