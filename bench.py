@@ -314,7 +314,7 @@ def main():
             "phase_ms": phase_avg,
             "residual_std": resid_std,
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:         # reported baseline: rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000)
         print(json.dumps(result), flush=True)
 
