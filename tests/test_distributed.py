@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from util import synth_volume
 
-from aind_exaspim_image_compression.distributed import SlabPlan, plan_slabs
+from aind_exaspim_image_compression.distributed import plan_slabs
 
 SIGMA = 24.0
 SHAPE = (112, 24, 28)

@@ -2,7 +2,6 @@
 import os
 import sys
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aind-exaspim-image-compression_amd"))
