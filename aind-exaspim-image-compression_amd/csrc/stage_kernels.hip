@@ -18,6 +18,8 @@
 //       L3: lane = (x,y), regs = z    spectrum layout
 // All DCT arithmetic is the even/odd-folded 4-term fmaf chain of DESIGN.md 3.5 and is
 // bit-identical to the oracle; only the order of the atomic sums differs.
+#include <algorithm>
+
 #include "exabm4d_kernels.h"
 #include "dct_pairs.h"
 
@@ -1207,7 +1209,14 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         if (e != hipSuccess) return e;
         const int hty = (g.gy + HTY - 1) / HTY;
         const long long htiles = (long long)hty * tiles_x * batch;
+        // z chunks: at least ~4 work items per CU, and -- while a chunk keeps >= 16 layers, so that
+        // its ring start-up and final flush stay small -- about 128 per CU: a 1024^3 volume has
+        // only 21 tile columns per CU and the last ones leave most of the chip idle (measured at
+        // 1024^3: 1 chunk 242 / 352 ms, 8 chunks 237 / 339 ms, 32 chunks 245 / 345 ms; 512^3:
+        // 1 chunk 33.7 / 48.3 ms, 7 chunks 30.9 / 43.7 ms).
         int hchunks = (int)((1024 + htiles - 1) / htiles);
+        const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
+        if (hchunks < fine) hchunks = fine;
         if (hchunks < 1) hchunks = 1;
         if (hchunks > g.gz) hchunks = g.gz;
         const int hlpc = (g.gz + hchunks - 1) / hchunks;

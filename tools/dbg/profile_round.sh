@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r01b; mkdir -p $O
+O=gpurun_out/prof_round; rm -rf $O; mkdir -p $O
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -1 $O/gpu_tests.log
 timeout -k 10 300 python tools/stress_stage.py 384 > $O/stress.log 2>&1; tail -1 $O/stress.log
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
