@@ -153,16 +153,73 @@ __device__ __forceinline__ void load8p(const f2* p, f2 (&v)[8]) {
 }
 
 
+// ---- lo <-> register transposition without LDS ----------------------------------------------------
+// Within every group of 8 lanes (same hi), lane a / register b holds X[a][b] before and X[b][a]
+// after: three butterfly stages over the index bits 4, 2, 1, each swapping X[l][r] with
+// X[l ^ bit][r ^ bit] where the lane's and the register's bit differ.  Bit 4 is a DPP row shift
+// written under a bank mask (one instruction per register), bits 2 and 1 are quad permutes plus a
+// select.  Data movement only: bit-identical to the LDS round trip it replaces.
+#ifndef EXABM4D_DPP_TR
+#define EXABM4D_DPP_TR 0
+#endif
+template <int CTRL>
+__device__ __forceinline__ float dpp_qp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void tr_bit4(float& A, float& B) {
+    const int a = __float_as_int(A), b = __float_as_int(B);
+    // lanes 4-7 of a group (banks 1, 3): A <- B of lane - 4;  lanes 0-3 (banks 0, 2): B <- A of lane + 4
+    A = __int_as_float(__builtin_amdgcn_update_dpp(a, b, 0x114 /* row_shr:4 */, 0xF, 0xA, false));
+    B = __int_as_float(__builtin_amdgcn_update_dpp(b, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false));
+}
+template <int CTRL>
+__device__ __forceinline__ void tr_quad(float& A, float& B, bool bitset) {
+    const float pa = dpp_qp<CTRL>(A), pb = dpp_qp<CTRL>(B);
+    A = bitset ? pb : A;
+    B = bitset ? B : pa;
+}
+__device__ __forceinline__ void transpose_lo(f2 (&v)[8], int lo) {
+    const bool b2 = (lo & 2) != 0, b1 = (lo & 1) != 0;
+    float x[8], y[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        x[r] = v[r].x;
+        y[r] = v[r].y;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {              // bit 4: registers r, r + 4
+        tr_bit4(x[r], x[r + 4]);
+        tr_bit4(y[r], y[r + 4]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {              // bit 2: registers r, r + 2 with (r & 2) == 0
+        const int r = (q & 1) | ((q & 2) << 1);
+        tr_quad<0x4E>(x[r], x[r + 2], b2);     // quad_perm [2,3,0,1]
+        tr_quad<0x4E>(y[r], y[r + 2], b2);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {              // bit 1: registers 2 q, 2 q + 1
+        tr_quad<0xB1>(x[2 * q], x[2 * q + 1], b1);   // quad_perm [1,0,3,2]
+        tr_quad<0xB1>(y[2 * q], y[2 * q + 1], b1);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = mk2(x[r], y[r]);
+}
+
 // 3-D DCT of TWO blocks at once (streams .x / .y; the transpose buffer holds float2 elements).
 // In: layout L1, out: L3.
 template <typename TableT>
 __device__ __forceinline__ void pair_fwd(const TableT& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_fwd2(T, v);                                             // along y
+#if EXABM4D_DPP_TR
+    transpose_lo(v, lo);                                         // L2: hi = z, lo = y, regs x
+#else
 #pragma unroll
     for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = v[y];  // buffer [z][y][x]
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
     cbar();
+#endif
     dct8_fwd2(T, v);                                             // along x
 #pragma unroll
     for (int x = 0; x < 8; x++) tb[x * TSI + lo * TSJ + hi] = v[x];  // buffer [x][y][z]
@@ -182,11 +239,15 @@ __device__ __forceinline__ void pair_inv(const TableT& T, f2* tb, int hi, int lo
     load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
     cbar();
     dct8_inv2(T, v);                                             // along x
+#if EXABM4D_DPP_TR
+    transpose_lo(v, lo);                                         // L1: hi = z, lo = x, regs y
+#else
 #pragma unroll
     for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = v[x];  // buffer [z][x][y]
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, v);                         // L1: hi = z, lo = x, regs y
     cbar();
+#endif
     dct8_inv2(T, v);                                             // along y
 }
 
