@@ -48,7 +48,7 @@ constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
-                                                      int tiles_x) {
+                                                      int tiles_x, int guarded) {
     __shared__ __align__(16) float pbuf_all[TC][2][PBUF];
 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
@@ -68,8 +68,13 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
               qx = min(STEP * ix, g.nx - STEP);
     // Tile origin (voxels) of the staged window; wave-uniform.
     const int Y0 = STEP * TR * ty, X0 = STEP * TR * tx - RAD, Z0 = STEP * (TR * tz + cz);
-    // Whole staged column range inside the volume?  (wave-uniform; edge tiles clamp per element)
-    const bool xin = (X0 >= 0) && (X0 + PCOLS - 1 <= g.nx - 1);
+    // Whole staged column range inside the volume?  (wave-uniform; edge tiles clamp per element.)
+    // `guarded`: the volume is one of the library's own buffers, with >= 256 bytes of mapped memory
+    // on either side.  Columns outside the volume then need no clamping at all: they only ever
+    // enter the distances of candidates that lie partly outside the volume, which `valid` masks
+    // (a block inside the volume has all its columns inside), so x-edge tiles can take the
+    // LDS-DMA path too and read whatever lies beyond the row ends.
+    const bool xin = guarded || ((X0 >= 0) && (X0 + PCOLS - 1 <= g.nx - 1));
 
     const bool ref_ok = cx < TR && cy < TR && cz < TR && iz < g.az && iy < g.ay && ix < g.ax;
     const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
@@ -351,11 +356,12 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // host launchers (called from exabm4d_api.cpp)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
-                             uint32_t* keys, hipStream_t stream, int force_generic) {
+                             uint32_t* keys, hipStream_t stream, int force_generic, int guarded) {
     if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
         const int tz = (g.az + TR - 1) / TR, ty = (g.ay + TR - 1) / TR, tx = (g.ax + TR - 1) / TR;
         dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
-        hipLaunchKernelGGL(bm_tile_kernel, grid, dim3(512), 0, stream, vol, g, keymax, keys, ty, tx);
+        hipLaunchKernelGGL(bm_tile_kernel, grid, dim3(512), 0, stream, vol, g, keymax, keys, ty, tx,
+                           guarded);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -28,6 +28,7 @@ struct exabm4d_ctx {
     void* red = nullptr;       // metric entry points: histogram / partials / results
     size_t red_bytes = 0;
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
+    int bm_guarded_copy = 0;   // exabm4d_set_option("bm_guarded_copy"): staged block matching on a guarded copy
     int stage_pairs = 1;       // exabm4d_set_option("stage_pairs"): two waves per group (HT stage)
     int profile = 0;           // exabm4d_set_option("profile")
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
@@ -130,7 +131,9 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
-    hipError_t e = hipMalloc(&ctx->scratch, bytes);
+    // + 256: block matching reads up to 124 bytes past the last row of the library's own volumes
+    // (bm_tile_kernel, `guarded`); the region in front of each of them is another scratch region
+    hipError_t e = hipMalloc(&ctx->scratch, bytes + 256);
     if (e != hipSuccess) {
         char msg[160];
         std::snprintf(msg, sizeof msg, "device scratch allocation of %zu bytes failed: %s", bytes,
@@ -265,6 +268,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->force_generic_bm = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "bm_guarded_copy") == 0) {
+        ctx->bm_guarded_copy = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "stage_pairs") == 0) {
         ctx->stage_pairs = value ? 1 : 0;
         return EXABM4D_OK;
@@ -373,8 +380,22 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
     rc = make_geom(ctx, nz, ny, nx, batch, g);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->bm_guarded_copy) {
+        // parity hook for the pipeline's path: match on a copy inside the scratch allocation, with
+        // 256 bytes of poison on either side, through the kernel's `guarded` variant
+        const size_t bytes = (size_t)g.nvox * (size_t)batch * sizeof(float);
+        rc = ensure_scratch(ctx, bytes + 512);
+        if (rc) return rc;
+        char* base = static_cast<char*>(ctx->scratch);
+        HIP_TRY(ctx, hipMemsetAsync(base, 0xFF, bytes + 512, ctx->stream));      // NaN bit patterns
+        HIP_TRY(ctx, hipMemcpyAsync(base + 256, vol, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(ctx, launch_blockmatch(reinterpret_cast<const float*>(base + 256), g, batch,
+                                       keymax_of(sigma, c_match), keys, ctx->stream,
+                                       ctx->force_generic_bm, 1));
+        return EXABM4D_OK;
+    }
     HIP_TRY(ctx, launch_blockmatch(vol, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm));
+                                   ctx->force_generic_bm, 0));
     return EXABM4D_OK;
 }
 
@@ -453,7 +474,10 @@ struct PhaseTimer {
 // noisy: fp32 counts on device.  Exactly one of out_f32 / out_u16 is written.
 static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, uint16_t* out_u16,
                         const VolGeom& g, int batch, float sigma, const exabm4d_params* p,
-                        int stages, float clip_lo, float clip_hi, float u16_offset, char* scratch) {
+                        int stages, float clip_lo, float clip_hi, float u16_offset, char* scratch,
+                        int noisy_guarded) {
+    // noisy_guarded: `noisy` lies inside the scratch allocation (mapped memory on both sides, see
+    // ensure_scratch and bm_tile_kernel); a caller's own device buffer is not assumed to.
     const size_t n = (size_t)g.nvox * (size_t)batch;
     uint32_t* keys = reinterpret_cast<uint32_t*>(scratch);
     scratch += align256((size_t)g.nref * (size_t)batch * MAXG * sizeof(uint32_t));
@@ -481,7 +505,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);
         HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
-                                       ctx->force_generic_bm));
+                                       ctx->force_generic_bm, noisy_guarded));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
@@ -502,7 +526,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
             HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys,
-                                           s, ctx->force_generic_bm));
+                                           s, ctx->force_generic_bm, 1));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
@@ -543,7 +567,7 @@ int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int n
     rc = ensure_scratch(ctx, exabm4d_scratch_bytes(nz, ny, nx, batch, stages));
     if (rc) return rc;
     return run_pipeline(ctx, in, out, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
-                        static_cast<char*>(ctx->scratch));
+                        static_cast<char*>(ctx->scratch), 0);
 }
 
 int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
@@ -564,7 +588,7 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
         HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream));
     }
     return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
-                        scratch);
+                        scratch, 1);
 }
 
 int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
@@ -581,7 +605,7 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     float* vol = reinterpret_cast<float*>(scratch + base);
     HIP_TRY(ctx, hipMemcpyAsync(vol, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
-                      scratch);
+                      scratch, 1);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -111,7 +111,10 @@ int exabm4d_default_params(exabm4d_params* p);
  * one-wave-per-block matching kernel (normally used only for grid points that are not a
  * multiple of 4); the parity tests use it to check the two kernels against each other.
  * "stage_pairs" = 0 selects the one-wave-per-group stage kernels instead of the default
- * two-waves-per-group ones (same arithmetic; kept as a cross-check). */
+ * two-waves-per-group ones (same arithmetic; kept as a cross-check).
+ * "bm_guarded_copy" = 1 makes exabm4d_blockmatch_dev match on a copy of the volume inside the
+ * library's scratch allocation, the way the exabm4d_denoise_* pipelines do (x-edge tiles then
+ * stream their planes by LDS-DMA without clamping); for the parity tests. */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
 /* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
  * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and

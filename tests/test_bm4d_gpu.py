@@ -34,6 +34,30 @@ def test_blockmatch_bit_exact(ctx, oracle, shape):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("shape", [(64, 64, 64), (54, 54, 54), (8, 8, 8), (16, 12, 36),
+                                   (30, 37, 41), (9, 10, 100)])
+def test_blockmatch_on_guarded_copy_bit_exact(ctx, oracle, shape):
+    """The pipelines match on the library's own buffers, where x-edge tiles skip the per-element
+    clamping and read past the row ends (poisoned with NaN patterns here): same match tables."""
+    vol, _ = synth_volume(shape, seed=sum(shape) + 1)
+    want = oracle.blockmatch(vol, SIGMA, 3.0)
+    ctx.set_option("bm_guarded_copy", 1)
+    try:
+        got = _keys_gpu(ctx, vol, SIGMA, 3.0)
+        batch = np.stack([vol, vol[::-1].copy()])
+        g = got.shape[:3]
+        d_vol = ctx.to_device(batch)
+        d_keys = ctx.alloc(2 * g[0] * g[1] * g[2] * 16 * 4)
+        ctx.blockmatch(d_vol, vol.shape, SIGMA, 3.0, d_keys, batch=2)
+        ctx.sync()
+        both = d_keys.download((2,) + got.shape, np.uint32)
+    finally:
+        ctx.set_option("bm_guarded_copy", 0)
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(both[0], want)
+    np.testing.assert_array_equal(both[1], oracle.blockmatch(batch[1], SIGMA, 3.0))
+
+
 def test_blockmatch_generic_kernel_matches(ctx, oracle):
     """The one-wave-per-block kernel alone must also reproduce the oracle bit for bit."""
     vol, _ = synth_volume((36, 40, 44), seed=5)
