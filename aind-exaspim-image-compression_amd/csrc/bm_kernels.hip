@@ -23,17 +23,28 @@ struct __attribute__((packed, aligned(4))) float4u {
     float x, y, z, w;
 };
 
-constexpr int TC = 8;        // cells per tile edge
-constexpr int TR = TC - 1;   // reference blocks per tile edge
+constexpr int TCZ = 8;       // cell layers per tile = waves per workgroup
+constexpr int TRZ = TCZ - 1; // reference layers per tile
 constexpr int NE = 6;        // dy values per pass (two passes: dy = -5..0 and 1..6, 6 is masked)
-constexpr int PROWS = 4 * (TC - 1) + 3 + NE;   // 37 staged rows: 4*cy + y + e
-constexpr int PCOLS = 4 * (TC - 1) + 16;       // 44 staged columns: 4*cx + 0..15
-constexpr int PSTR = 56;     // row stride in floats: 8 (mod 16) makes the b128 window reads
-                             // of lanes (cy,cx) conflict-free
-constexpr int PCH = PSTR / 4;                   // 16-byte chunks per staged row (14, 11 used)
-constexpr int NDMA = (PROWS * PCH + 63) / 64;   // LDS-DMA instructions per plane (9 x 1 KiB)
-constexpr int PBUF = NDMA * 256;                // floats per plane buffer (2304)
 constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
+// A wave is one z-layer of TCY x TCX cells (64 lanes).  8 x 8 is the shape for volumes; 4 x 16
+// tiles a 64^3 patch (15 reference positions per axis) exactly in x (15) and y (5 x 3), where the
+// cube needs 3 x 3 tiles of 7 x 7 positions for the same 15 x 15.
+template <int TCY_, int TCX_>
+struct TileShape {
+    static constexpr int TCY = TCY_, TCX = TCX_;
+    static constexpr int TRY = TCY - 1, TRX = TCX - 1;      // reference blocks per tile edge
+    static constexpr int PROWS = 4 * (TCY - 1) + 3 + NE;    // staged rows: 4*cy + y + e (37 / 21)
+    static constexpr int PCOLS = 4 * (TCX - 1) + 16;        // staged columns: 4*cx + 0..15 (44 / 76)
+    // row stride in floats.  8 x 8: 56 = 8 (mod 16) makes the b128 window reads of the two cell
+    // rows that share 16 lanes conflict-free; 4 x 16: 16 lanes are one cell row, any stride does.
+    static constexpr int PSTR = TCX == 8 ? 56 : PCOLS;
+    static constexpr int PCH = PSTR / 4;                    // 16-byte chunks per staged row
+    static constexpr int NDMA = (PROWS * PCH + 63) / 64;    // LDS-DMA instructions per plane
+    // floats per plane buffer; also holds the cell-sum exchange: 33 sums x 64 cells
+    static constexpr int PBUF = NDMA * 256 > 2304 ? NDMA * 256 : 2304;
+    static_assert(TCY * TCX == 64 && PCOLS % 4 == 0 && PSTR % 4 == 0, "one wave per cell layer");
+};
 
 // Each WAVE (= one z-layer of 8x8 cells) streams the candidate planes it needs through its own
 // pair of LDS buffers: for a fixed dz and a pass of NE dy values, plane z+dz of the volume
@@ -45,11 +56,14 @@ constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
 // 1.8 TB of fabric traffic per 1024^3 launch at 7 TB/s -- bandwidth-bound on re-reads).
 // The cell-sum exchange buffer aliases the waves' current plane buffers (each wave publishes the
 // sums of its own 64 cells in its own buffer once its reads of the plane are done).
+template <class TS>
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
                                                       int tiles_x, int guarded) {
-    __shared__ __align__(16) float pbuf_all[TC][2][PBUF];
+    constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS,
+                  PCOLS = TS::PCOLS, PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
+    __shared__ __align__(16) float pbuf_all[TCZ][2][PBUF];
 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
@@ -57,9 +71,9 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
-    const int cx = tid & 7, cy = (tid >> 3) & 7, cz = tid >> 6;      // cz == wave index
     const int lane = tid & 63;
-    const int ix = TR * tx + cx, iy = TR * ty + cy, iz = TR * tz + cz;  // cell == ref index
+    const int cx = lane % TCX, cy = lane / TCX, cz = tid >> 6;       // cz == wave index
+    const int ix = TRX * tx + cx, iy = TRY * ty + cy, iz = TRZ * tz + cz;  // cell == ref index
 
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
@@ -67,7 +81,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const int qz = min(STEP * iz, g.nz - STEP), qy = min(STEP * iy, g.ny - STEP),
               qx = min(STEP * ix, g.nx - STEP);
     // Tile origin (voxels) of the staged window; wave-uniform.
-    const int Y0 = STEP * TR * ty, X0 = STEP * TR * tx - RAD, Z0 = STEP * (TR * tz + cz);
+    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD, Z0 = STEP * (TRZ * tz + cz);
     // Whole staged column range inside the volume?  (wave-uniform; edge tiles clamp per element.)
     // `guarded`: the volume is one of the library's own buffers, with >= 256 bytes of mapped memory
     // on either side.  Columns outside the volume then need no clamping at all: they only ever
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // LDS-DMA path too and read whatever lies beyond the row ends.
     const bool xin = guarded || ((X0 >= 0) && (X0 + PCOLS - 1 <= g.nx - 1));
 
-    const bool ref_ok = cx < TR && cy < TR && cz < TR && iz < g.az && iy < g.ay && ix < g.ax;
+    const bool ref_ok = cx < TRX && cy < TRY && cz < TRZ && iz < g.az && iy < g.ay && ix < g.ax;
     const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
 
     uint32_t list[MAXG];
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
             float* mine = cur + lane;
             const float* lo_w = cur + lane;                                  // cells of wave cz
-            const float* hi_w = pbuf_all[min(cz + 1, TC - 1)][step & 1] + lane;  // wave cz + 1
+            const float* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;  // wave cz + 1
             // NE / 2 dy values per round (33 sums per cell fit the 36 slots of a plane buffer):
             // two barrier pairs per pass instead of six.  Each cell lane first adds its
             // x-neighbour's sum (DPP row_shl:1, no LDS), so a reference lane reads 4 values per
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                             for (int d = 0; d < SWIN; d++) {
                                 const float* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
                                 const float* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
-                                const float S = (c0[0] + c0[8]) + (c1[0] + c1[8]);
+                                const float S = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]);
                                 const uint32_t code = (d == RAD && self_row) ? 0u : cbase + d;
                                 const bool valid = vzy && ((xmask >> d) & 1u);
                                 uint32_t key = (__float_as_uint(S) & KEY_DMASK) | code;
@@ -358,10 +372,22 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded) {
     if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
-        const int tz = (g.az + TR - 1) / TR, ty = (g.ay + TR - 1) / TR, tx = (g.ax + TR - 1) / TR;
+        using Cube = TileShape<8, 8>;
+        using Flat = TileShape<4, 16>;
+        auto tiles = [&](int try_, int trx) {
+            return (long long)((g.ay + try_ - 1) / try_) * ((g.ax + trx - 1) / trx);
+        };
+        // fewer (y, x) tiles = fewer idle cell lanes (64^3 patches: 5 flat tiles against 9 cubes)
+        const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
+        const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
+        const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
         dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
-        hipLaunchKernelGGL(bm_tile_kernel, grid, dim3(512), 0, stream, vol, g, keymax, keys, ty, tx,
-                           guarded);
+        if (flat)
+            hipLaunchKernelGGL(bm_tile_kernel<Flat>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
+                               ty, tx, guarded);
+        else
+            hipLaunchKernelGGL(bm_tile_kernel<Cube>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
+                               ty, tx, guarded);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
