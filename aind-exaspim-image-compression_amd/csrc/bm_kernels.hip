@@ -138,6 +138,14 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
         }
     };
 
+    // A wave whose cell layer lies beyond the last one any reference block uses (layers 0 .. az)
+    // has nothing to contribute -- the last z tile of a 64^3 patch needs 2 of its 8 layers -- and
+    // only keeps the workgroup's barrier count: four per (dz, pass).
+    if (TRZ * tz + cz > g.az) {
+        for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
+        return;
+    }
+
     if (xin)
         issue_dma(0, pbuf_all[cz][0]);
     else
