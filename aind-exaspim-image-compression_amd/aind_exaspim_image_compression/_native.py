@@ -114,6 +114,11 @@ SIGNATURES = {
     "exabm4d_dctq_forward_dev": (_I, [_CTX, c_vp, _I, _I, _I, ctypes.c_float, c_vp]),
     "exabm4d_dctq_inverse_dev": (_I, [_CTX, c_vp, _I, _I, _I, ctypes.c_float, c_vp]),
     "exabm4d_i32_symbol_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
+    "exabm4d_codec_chunk_bound": (_SZ, [_SZ, _I]),
+    "exabm4d_codec_volume_bound": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    "exabm4d_codec_encode_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp, _SZ, c_vp, c_vp,
+                                      c_vp]),
+    "exabm4d_codec_decode_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp]),
     "exabm4d_u16_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
     "exabm4d_key_histogram_dev": (_I, [_CTX, c_vp, _I, _SZ, _I, ctypes.c_double, _I,
                                        ctypes.c_uint64, c_vp]),
@@ -391,6 +396,25 @@ class Context:
         self._check(lib().exabm4d_dctq_inverse_dev(self.handle, _ptr(idx), nz, ny, nx, float(q),
                                                    _ptr(vol)))
 
+    # -- chunk entropy coder (row f-1) ------------------------------------------------------------
+    def codec_encode(self, vol, typesize, shape, chunk, out=None, out_capacity=0, offsets=None,
+                     sizes=None, totals=True):
+        """Code every chunk of a device volume.  -> (sum of stream lengths, container bytes) when
+        `totals` (synchronises), else None."""
+        nz, ny, nx = shape
+        tot = np.zeros(2, dtype=np.uint64)
+        self._check(lib().exabm4d_codec_encode_dev(
+            self.handle, _ptr(vol), int(typesize), nz, ny, nx, int(chunk[0]), int(chunk[1]),
+            int(chunk[2]), _ptr(out), int(out_capacity), _ptr(offsets), _ptr(sizes),
+            tot.ctypes.data_as(c_vp) if totals else None))
+        return (int(tot[0]), int(tot[1])) if totals else None
+
+    def codec_decode(self, data, offsets, typesize, shape, chunk, vol):
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_codec_decode_dev(
+            self.handle, _ptr(data), _ptr(offsets), int(typesize), nz, ny, nx, int(chunk[0]),
+            int(chunk[1]), int(chunk[2]), _ptr(vol)))
+
     # -- background offset + quality metrics (row f-4); inputs on device, scalars to the host ----
     DTYPES = {np.dtype(np.uint16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
 
@@ -466,6 +490,20 @@ def device_count():
 
 
 # -- host-only helpers (no GPU) -----------------------------------------------------------------
+def codec_chunk_bound(n, typesize):
+    return int(lib().exabm4d_codec_chunk_bound(int(n), int(typesize)))
+
+
+def codec_volume_bound(typesize, shape, chunk):
+    b = int(lib().exabm4d_codec_volume_bound(int(typesize), int(shape[0]), int(shape[1]),
+                                             int(shape[2]), int(chunk[0]), int(chunk[1]),
+                                             int(chunk[2])))
+    if b == 0:
+        raise ValueError("codec: typesize must be 2 or 4 and every size >= 1")
+    return b
+
+
+
 def grid_positions(n):
     c = lib().exabm4d_grid_count(int(n))
     pos = np.zeros(max(c, 0), dtype=np.int32)

@@ -1,0 +1,168 @@
+"""Chunk entropy coder of the encode half (BASELINE config 5).
+
+The reference measures its compression ratio by handing every C-order 64^3 chunk of the uint16
+volume to a codec object, ``len(codec.encode(chunk))`` (reference ``utils/img_util.py:401-441``);
+the object it passes is ``numcodecs.blosc.Blosc(cname="zstd", clevel=5|6, shuffle=SHUFFLE)``
+(``evaluate.py:40``, ``train.py:105``, ``scripts/evaluate_bm4dnet.py:140``) and the same codec
+compresses the chunks ``write_zarr`` stores (``utils/img_util.py:935-950``).  ``ShuffleRansCodec``
+is an object of that shape -- ``encode(buf) -> bytes``, ``decode(bytes) -> ndarray`` -- whose
+arithmetic runs on the MI355X: Blosc's byte shuffle followed by a static order-0 rANS coder per
+byte plane (EXAC v1; zstd itself is third-party and absent, so the byte counts are
+this codec's, not Blosc's).  Besides the per-chunk calls it codes all chunks of a volume that is
+already in HBM with one kernel sequence (``encode_volume``), which is what ``compute_cratio`` uses
+when it is given this codec.
+"""
+import numpy as np
+
+from aind_exaspim_image_compression import _native
+
+_DTYPES = {2: np.dtype(np.uint16), 4: np.dtype(np.int32)}
+
+
+def _typesize(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.uint16:
+        return 2
+    if dtype == np.int32:
+        return 4
+    raise ValueError("ShuffleRansCodec codes uint16 or int32 elements, not %s" % dtype)
+
+
+def _shape3(shape):
+    shape = tuple(int(s) for s in shape)
+    if len(shape) > 3:
+        lead = int(np.prod(shape[:-3]))
+        if lead != 1:
+            raise ValueError("expected at most three non-trivial axes")
+        shape = shape[-3:]
+    return (1,) * (3 - len(shape)) + shape
+
+
+class EncodedVolume:
+    """All chunk streams of one volume: ``data`` (uint8 container, every stream starting at a
+    multiple of 16 bytes), ``offsets`` (uint64, nchunks + 1), ``sizes`` (uint32, exact stream
+    lengths = ``len(codec.encode(chunk))``), chunks in (z, y, x) raster order."""
+
+    def __init__(self, data, offsets, sizes, shape, chunk, typesize):
+        self.data = data
+        self.offsets = offsets
+        self.sizes = sizes
+        self.shape = tuple(shape)
+        self.chunk = tuple(chunk)
+        self.typesize = int(typesize)
+
+    @property
+    def nbytes(self):
+        """Sum of the chunk stream lengths (the denominator of the compression ratio)."""
+        return int(self.sizes.sum(dtype=np.uint64))
+
+    def chunk_bytes(self, i):
+        o = int(self.offsets[i])
+        return self.data[o:o + int(self.sizes[i])].tobytes()
+
+
+class ShuffleRansCodec:
+    """numcodecs-shaped codec: byte shuffle + per-plane order-0 rANS on the GPU."""
+
+    codec_id = "exac-shuffle-rans"
+
+    def __init__(self, typesize=2, device=None):
+        if typesize not in (2, 4):
+            raise ValueError("typesize must be 2 (uint16) or 4 (int32)")
+        self.typesize = int(typesize)
+        self.device = device
+
+    def get_config(self):
+        return {"id": self.codec_id, "typesize": self.typesize}
+
+    # -- one chunk ---------------------------------------------------------------------------
+    def encode(self, buf):
+        """One chunk (any shape; coded in C order) -> bytes."""
+        a = np.ascontiguousarray(buf)
+        if _typesize(a.dtype) != self.typesize:
+            raise ValueError("element type does not match the codec's typesize")
+        if a.size == 0:
+            raise ValueError("cannot encode an empty chunk")
+        shape = (1, 1, a.size)
+        enc = self.encode_volume(a.reshape(shape), chunk=shape)
+        return enc.chunk_bytes(0)
+
+    def decode(self, buf, out=None):
+        """bytes of one chunk -> 1-D array (or filled ``out``) of the codec's element type."""
+        raw = np.frombuffer(bytes(buf), dtype=np.uint8)
+        if raw.size < 8 or raw[0] != ord("E") or raw[1] != ord("X") or raw[3] != self.typesize:
+            raise ValueError("not an EXAC stream of this codec's typesize")
+        n = int(raw[4:8].view("<u4")[0])
+        if n == 0:
+            raise ValueError("empty EXAC stream")
+        shape = (1, 1, n)
+        pad = (-raw.size) % 16
+        data = np.concatenate([raw, np.zeros(pad, np.uint8)]) if pad else raw
+        enc = EncodedVolume(data, np.array([0, data.size], dtype=np.uint64),
+                            np.array([raw.size], dtype=np.uint32), shape, shape, self.typesize)
+        res = self.decode_volume(enc).reshape(-1)
+        if out is not None:
+            np.copyto(np.asarray(out).reshape(-1), res)
+            return out
+        return res
+
+    # -- a whole volume ------------------------------------------------------------------------
+    def encode_volume(self, vol, chunk=(64, 64, 64), want_bytes=True):
+        """Host array (uint16 / int32, up to 3-D) -> ``EncodedVolume`` on the host.  With
+        ``want_bytes=False`` only the sizes are produced (``data`` is None)."""
+        a = np.ascontiguousarray(vol)
+        if _typesize(a.dtype) != self.typesize:
+            raise ValueError("element type does not match the codec's typesize")
+        shape = _shape3(a.shape)
+        ctx = _native.context(self.device)
+        d_vol = ctx.to_device(a.reshape(-1))
+        try:
+            return self.encode_device(ctx, d_vol, shape, chunk, want_bytes)
+        finally:
+            d_vol.free()
+
+    def encode_device(self, ctx, d_vol, shape, chunk=(64, 64, 64), want_bytes=True):
+        """The same for a volume that already lies in HBM (``d_vol``: device pointer holder)."""
+        shape = _shape3(shape)
+        chunk = tuple(min(int(c), s) for c, s in zip(_shape3(chunk), shape))
+        nchunks = int(np.prod([-(-s // c) for s, c in zip(shape, chunk)]))
+        d_sizes = ctx.alloc(4 * nchunks)
+        d_off = ctx.alloc(8 * (nchunks + 1))
+        d_out = None
+        try:
+            cap = 0
+            if want_bytes:
+                cap = _native.codec_volume_bound(self.typesize, shape, chunk)
+                d_out = ctx.alloc(cap)
+            _, container = ctx.codec_encode(d_vol, self.typesize, shape, chunk, out=d_out,
+                                            out_capacity=cap, offsets=d_off, sizes=d_sizes)
+            sizes = d_sizes.download((nchunks,), np.uint32)
+            offsets = d_off.download((nchunks + 1,), np.uint64)
+            data = d_out.download((container,), np.uint8) if want_bytes else None
+        finally:
+            d_sizes.free()
+            d_off.free()
+            if d_out is not None:
+                d_out.free()
+        return EncodedVolume(data, offsets, sizes, shape, chunk, self.typesize)
+
+    def decode_volume(self, enc):
+        """``EncodedVolume`` -> host array of ``enc.shape``."""
+        if enc.typesize != self.typesize:
+            raise ValueError("EncodedVolume of another typesize")
+        ctx = _native.context(self.device)
+        d_in = ctx.to_device(enc.data)
+        d_off = ctx.to_device(np.ascontiguousarray(enc.offsets, dtype=np.uint64))
+        n = int(np.prod(enc.shape))
+        d_vol = ctx.alloc(n * self.typesize)
+        try:
+            ctx.codec_decode(d_in, d_off, self.typesize, enc.shape, enc.chunk, d_vol)
+            return d_vol.download(enc.shape, _DTYPES[self.typesize])
+        finally:
+            d_in.free()
+            d_off.free()
+            d_vol.free()
+
+    def chunk_sizes(self, vol, chunk=(64, 64, 64)):
+        """``len(self.encode(c))`` of every chunk of ``vol``, one batched device call."""
+        return self.encode_volume(vol, chunk, want_bytes=False).sizes

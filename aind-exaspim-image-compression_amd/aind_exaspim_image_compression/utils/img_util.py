@@ -6,7 +6,11 @@ ratio rounded to two decimals.  The codec is whatever object the caller passes -
 passes ``numcodecs.blosc.Blosc(cname="zstd", clevel=5|6, shuffle=SHUFFLE)`` (``evaluate.py:40``,
 ``scripts/evaluate_bm4dnet.py:140``), which is third-party and not part of this repo.
 
-``shuffled_entropy_cratio`` is the MI355X-side rate proxy: a HIP kernel builds, per 64^3 chunk,
+``utils.chunk_codec.ShuffleRansCodec`` is a codec object of that shape whose arithmetic runs on
+the MI355X (byte shuffle + order-0 rANS per byte plane); given it, ``compute_cratio`` codes all
+chunks in one batched device call.
+
+``shuffled_entropy_cratio`` is the MI355X-side rate floor of that codec: a HIP kernel builds, per 64^3 chunk,
 the histograms of the two byte planes Blosc's SHUFFLE filter produces; the zeroth-order entropy
 of those planes bounds what an order-0 entropy coder behind the shuffle can reach.  It is a proxy
 for rate-distortion sweeps that keeps the volume in HBM, NOT the Blosc/zstd byte count (zstd also
@@ -23,6 +27,10 @@ def compute_cratio(img, codec, patch_shape=(64, 64, 64)):
     if img.ndim == 5:
         img = img[0, 0]
     img = np.ascontiguousarray(img, dtype=np.uint16)
+    if img.ndim == 3 and hasattr(codec, "chunk_sizes"):
+        # a device codec (utils/chunk_codec.ShuffleRansCodec): all chunks in one batched call;
+        # the sizes are exactly len(codec.encode(chunk)) of the loop below
+        return round(img.nbytes / int(codec.chunk_sizes(img, patch_shape).sum(dtype=np.uint64)), 2)
     raw = 0
     packed = 0
     grids = [range(0, s, c) for s, c in zip(img.shape, patch_shape)]

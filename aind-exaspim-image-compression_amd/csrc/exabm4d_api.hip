@@ -25,6 +25,9 @@ struct exabm4d_ctx {
     double win_beta = -1.0;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
+    uint32_t* rcp_dev = nullptr;   // chunk coder: reciprocal table, [4097][2]
+    void* codec_aux = nullptr;     // chunk coder: sizes / offsets / totals / status
+    size_t codec_aux_bytes = 0;
     void* red = nullptr;       // metric entry points: histogram / partials / results
     size_t red_bytes = 0;
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
@@ -213,6 +216,8 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->red) (void)hipFree(ctx->red);
+    if (ctx->rcp_dev) (void)hipFree(ctx->rcp_dev);
+    if (ctx->codec_aux) (void)hipFree(ctx->codec_aux);
     if (ctx->win_dev) (void)hipFree(ctx->win_dev);
     if (ctx->tf_lut) (void)hipFree(ctx->tf_lut);
     for (int i = 0; i < 2 * EXABM4D_PHASE_COUNT; i++)
@@ -738,6 +743,97 @@ int exabm4d_dctq_inverse_dev(exabm4d_ctx* ctx, const int32_t* idx, int nz, int n
     float dct[64], win[512];
     make_tables(0.0, dct, win);
     HIP_TRY(ctx, launch_dctq_inverse(idx, nz, ny, nx, dct, q, vol, ctx->stream));
+    return EXABM4D_OK;
+}
+
+// ---- chunk entropy coder (row f-1) --------------------------------------------------------
+size_t exabm4d_codec_chunk_bound(size_t n_elems, int typesize) {
+    if (typesize != 2 && typesize != 4) return 0;
+    return codec_chunk_bound(n_elems, typesize);
+}
+size_t exabm4d_codec_volume_bound(int typesize, int nz, int ny, int nx, int cz, int cy, int cx) {
+    CodecGeom g;
+    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g)) return 0;
+    return codec_volume_bound(g);
+}
+// aux layout: sizes u32[nchunks] | offsets u64[nchunks + 1] | totals u64[2] | status u32[4]
+static int codec_aux(exabm4d_ctx* ctx, int nchunks, uint32_t*& sizes, unsigned long long*& offsets,
+                     unsigned long long*& totals, uint32_t*& status) {
+    const size_t a = align256((size_t)nchunks * 4), b = align256(((size_t)nchunks + 1) * 8);
+    const size_t need = a + b + 256 + 256;
+    if (ctx->codec_aux_bytes < need) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->codec_aux) (void)hipFree(ctx->codec_aux);
+        ctx->codec_aux = nullptr;
+        ctx->codec_aux_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->codec_aux, need));
+        ctx->codec_aux_bytes = need;
+    }
+    char* base = static_cast<char*>(ctx->codec_aux);
+    sizes = reinterpret_cast<uint32_t*>(base);
+    offsets = reinterpret_cast<unsigned long long*>(base + a);
+    totals = reinterpret_cast<unsigned long long*>(base + a + b);
+    status = reinterpret_cast<uint32_t*>(base + a + b + 256);
+    return EXABM4D_OK;
+}
+int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int nz, int ny, int nx,
+                             int cz, int cy, int cx, uint8_t* out, size_t out_capacity,
+                             uint64_t* offsets_dev, uint32_t* sizes_dev, uint64_t* totals_host) {
+    if (!ctx || !vol) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    CodecGeom g;
+    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g))
+        return fail(ctx, EXABM4D_ERR_INVALID, "codec: typesize must be 2 or 4, sizes >= 1, chunk <= 2^28 elements");
+    if (out && !offsets_dev) return fail(ctx, EXABM4D_ERR_INVALID, "codec: offsets_dev is required with out");
+    if (out && out_capacity < codec_volume_bound(g))
+        return fail(ctx, EXABM4D_ERR_INVALID, "codec: out_capacity is below exabm4d_codec_volume_bound()");
+    if (out && ((uintptr_t)out & 15)) return fail(ctx, EXABM4D_ERR_INVALID, "codec: out must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->rcp_dev) {
+        static uint32_t tab[4097 * 2];
+        codec_fill_rcp_table(tab);
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rcp_dev, sizeof tab));
+        HIP_TRY(ctx, hipMemcpy(ctx->rcp_dev, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
+    uint32_t *sizes, *status;
+    unsigned long long *offsets, *totals;
+    int rc = codec_aux(ctx, g.nchunks, sizes, offsets, totals, status);
+    if (rc) return rc;
+    rc = ensure_scratch(ctx, (size_t)g.nchunks * g.slot_bytes);
+    if (rc) return rc;
+    if (sizes_dev) sizes = sizes_dev;
+    if (offsets_dev) offsets = reinterpret_cast<unsigned long long*>(offsets_dev);
+    HIP_TRY(ctx, launch_rans_encode(vol, g, ctx->rcp_dev, static_cast<uint8_t*>(ctx->scratch), sizes,
+                                    offsets, totals, out, ctx->stream));
+    if (totals_host) {
+        HIP_TRY(ctx, hipMemcpyAsync(totals_host, totals, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return EXABM4D_OK;
+}
+int exabm4d_codec_decode_dev(exabm4d_ctx* ctx, const uint8_t* in, const uint64_t* offsets_dev,
+                             int typesize, int nz, int ny, int nx, int cz, int cy, int cx, void* vol) {
+    if (!ctx || !in || !offsets_dev || !vol) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    CodecGeom g;
+    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g))
+        return fail(ctx, EXABM4D_ERR_INVALID, "codec: typesize must be 2 or 4, sizes >= 1, chunk <= 2^28 elements");
+    if ((uintptr_t)in & 15) return fail(ctx, EXABM4D_ERR_INVALID, "codec: in must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t *sizes, *status;
+    unsigned long long *offsets, *totals;
+    int rc = codec_aux(ctx, g.nchunks, sizes, offsets, totals, status);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(status, 0, 16, ctx->stream));
+    HIP_TRY(ctx, launch_rans_decode(in, reinterpret_cast<const unsigned long long*>(offsets_dev), g, vol,
+                                    status, ctx->stream));
+    uint32_t st = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&st, status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (st) {
+        char msg[96];
+        std::snprintf(msg, sizeof msg, "codec: malformed chunk stream (status 0x%x)", st);
+        return fail(ctx, EXABM4D_ERR_INVALID, msg);
+    }
     return EXABM4D_OK;
 }
 

@@ -67,4 +67,26 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
                                    const float* win1d, int overwrite, hipStream_t s);
 
+// ---- chunk entropy coder (rans_kernels.hip) ----------------------------------------
+struct CodecGeom {
+    int ts;                  // element bytes: 2 (uint16) or 4 (int32, zigzag mapped)
+    int nz, ny, nx;          // volume, elements
+    int cz, cy, cx;          // chunk shape (clamped to the volume)
+    int gz, gy, gx;          // chunks per axis
+    int nchunks;
+    size_t slot_hdr;         // scratch slot of one chunk: header + tables ...
+    size_t slot_plane;       // ... then `ts` stream regions of this many bytes
+    size_t slot_bytes;
+};
+int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g);
+size_t codec_chunk_bound(size_t n, int ts);
+size_t codec_volume_bound(const CodecGeom& g);
+void codec_fill_rcp_table(uint32_t* tab /* [4097][2]: reciprocal, shift */);
+// sizes[nchunks], offsets[nchunks + 1], totals[2] are device arrays; out == nullptr skips the packing
+hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
+                              uint32_t* sizes, unsigned long long* offsets, unsigned long long* totals,
+                              uint8_t* out, hipStream_t s);
+hipError_t launch_rans_decode(const uint8_t* in, const unsigned long long* offsets, const CodecGeom& g,
+                              void* vol, uint32_t* status, hipStream_t s);
+
 }  // namespace exabm4d

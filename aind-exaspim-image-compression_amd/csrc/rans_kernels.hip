@@ -1,0 +1,575 @@
+// rans_kernels.hip -- chunk entropy coder of the encode half (BASELINE
+// config 5): byte shuffle + static order-0 rANS per byte plane, one 64^3 chunk per workgroup, one
+// wave per byte plane, the 64 lanes of the wave being the 64 interleaved rANS states of the EXAC v1
+// stream.  Replaces the arithmetic behind the reference's
+// `codec.encode(chunk)` loop in compute_cratio (utils/img_util.py:401-441; the reference's codec
+// is third-party Blosc-zstd with the SHUFFLE filter, evaluate.py:40).
+//
+// Integer work only: HBM/LDS-bound, no MFMA.  A row of a chunk (64 elements) is one coalesced
+// wave load; the emitted 16-bit words of a row are compacted with a ballot + mbcnt rank.
+#include "exabm4d_kernels.h"
+
+namespace exabm4d {
+
+namespace {
+
+constexpr uint32_t RANS_L = 1u << 15;
+constexpr int RANS_BITS = 12;
+constexpr uint32_t RANS_M = 1u << RANS_BITS;
+constexpr int HDR_TABLE = 32 + 512;   // bitmap + up to 256 frequencies, per plane, in a slot
+
+struct ChunkBox {
+    size_t base;        // element index of the chunk's first element in the volume
+    int ey, ex;         // extent of this chunk along y, x
+    uint32_t n;         // elements in this chunk
+};
+
+__device__ __forceinline__ ChunkBox chunk_box(const CodecGeom& g, int c) {
+    const int bx = c % g.gx, by = (c / g.gx) % g.gy, bz = c / (g.gx * g.gy);
+    const int z0 = bz * g.cz, y0 = by * g.cy, x0 = bx * g.cx;
+    const int ez = min(g.cz, g.nz - z0), ey = min(g.cy, g.ny - y0), ex = min(g.cx, g.nx - x0);
+    ChunkBox b;
+    b.base = ((size_t)z0 * g.ny + y0) * g.nx + x0;
+    b.ey = ey;
+    b.ex = ex;
+    b.n = (uint32_t)ez * (uint32_t)ey * (uint32_t)ex;
+    return b;
+}
+
+// element offset (in the volume, relative to the chunk's first element) of chunk element i
+__device__ __forceinline__ size_t elem_offset(const CodecGeom& g, const ChunkBox& b, uint32_t i) {
+    const uint32_t x = i % (uint32_t)b.ex, t = i / (uint32_t)b.ex;
+    const uint32_t y = t % (uint32_t)b.ey, z = t / (uint32_t)b.ey;
+    return ((size_t)z * g.ny + y) * g.nx + x;
+}
+
+template <int TS>
+__device__ __forceinline__ uint32_t load_bits(const void* vol, size_t e) {
+    if (TS == 2) return static_cast<const uint16_t*>(vol)[e];
+    const int32_t v = static_cast<const int32_t*>(vol)[e];
+    return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+}
+
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint32_t rank_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o, 64));
+    return v;
+}
+// exclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(s, o, 64);
+        if (lane >= (uint32_t)o) s += t;
+    }
+    return s - v;
+}
+
+// Normalised frequencies of one plane from its 256 counts (oracle
+// orc_exac_normalize).  Lane l owns symbols 64 j + l, j = 0..3.
+__device__ __forceinline__ void normalize_plane(const uint32_t (&cnt)[4], uint32_t n, uint32_t lane,
+                                                uint32_t (&F)[4]) {
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        F[j] = 0;
+        if (cnt[j]) {
+            const uint64_t f = ((uint64_t)cnt[j] * RANS_M + n / 2) / n;
+            F[j] = f < 1 ? 1u : (uint32_t)f;
+        }
+        mine += F[j];
+    }
+    uint32_t sum = wave_sum(mine);
+    for (;;) {
+        // largest F, lowest symbol on ties: key = F << 8 | (255 - s)
+        uint32_t key = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) key = max(key, (F[j] << 8) | (255u - (64u * j + lane)));
+        const uint32_t best = wave_max(key);
+        const uint32_t bs = 255u - (best & 255u);
+        const bool owner = (bs & 63u) == lane;
+        if (sum < RANS_M) {
+            if (owner) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((bs >> 6) == (uint32_t)j) F[j] += RANS_M - sum;
+            }
+            sum = RANS_M;
+        }
+        if (sum == RANS_M) break;
+        if (owner) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((bs >> 6) == (uint32_t)j) F[j] -= 1;
+        }
+        sum--;
+    }
+}
+
+}  // namespace
+
+// ---- encode: one workgroup per chunk, wave p codes byte plane p into the chunk's slot ---------------
+// Slot layout (scratch, worst case per chunk): [0, 8 + 4 TS) header, then TS table regions of
+// HDR_TABLE bytes, then at g.slot_hdr TS stream regions of g.slot_plane bytes.
+template <int TS>
+__global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __restrict__ vol, CodecGeom g,
+                                                             const uint2* __restrict__ rcp_tab,
+                                                             uint8_t* __restrict__ slots,
+                                                             uint32_t* __restrict__ sizes) {
+    __shared__ uint32_t hist[TS][256];
+    __shared__ uint2 etab[TS][256];
+    __shared__ uint32_t plane_bytes[TS];
+    const int c = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const int p = threadIdx.x >> 6;
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t n = b.n;
+    const uint32_t rows = (n + 63u) >> 6;
+    const bool fast = (b.ex == 64);       // a row of 64 elements is one x-row of the chunk
+    uint8_t* slot = slots + (size_t)c * g.slot_bytes;
+
+#pragma unroll
+    for (int j = 0; j < 4; j++) hist[p][64 * j + lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // -- pass 1: byte histogram of this wave's plane -------------------------------------------------
+    for (uint32_t r = 0; r < rows; r++) {
+        const uint32_t i = r * 64u + lane;
+        const bool act = i < n;
+        uint32_t s = 0;
+        if (act) {
+            const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
+                                    : elem_offset(g, b, i);
+            s = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
+        }
+        const uint64_t am = __ballot(act);
+        const uint32_t s0 = __builtin_amdgcn_readfirstlane(s);
+        const uint64_t same = __ballot(act && s == s0);
+        if (same == am) {                      // one symbol in the whole row: a single add
+            if (lane == (uint32_t)__builtin_ctzll(am)) atomicAdd(&hist[p][s0], (uint32_t)__popcll(am));
+        } else if (act) {
+            atomicAdd(&hist[p][s], 1u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // -- tables ------------------------------------------------------------------------------------
+    uint32_t cnt[4], F[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt[j] = hist[p][64 * j + lane];
+    normalize_plane(cnt, n, lane, F);
+
+    uint8_t* tab = slot + 8 + 4 * TS + p * HDR_TABLE;
+    uint32_t nsym = 0, cum = 0;
+    uint32_t C[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t pm = __ballot(F[j] != 0u);
+        if (lane == 0) reinterpret_cast<uint64_t*>(tab)[j] = pm;
+        if (F[j]) reinterpret_cast<uint16_t*>(tab + 32)[nsym + rank_below(pm)] = (uint16_t)F[j];
+        nsym += (uint32_t)__popcll(pm);
+        C[j] = cum + wave_excl_scan(F[j], lane);
+        cum += wave_sum(F[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint2 e = make_uint2(0u, 0u);
+        if (F[j]) {
+            const uint2 rs = rcp_tab[F[j]];    // {reciprocal, shift}
+            const uint32_t bias = F[j] == 1u ? C[j] + RANS_M - 1u : C[j];
+            e.x = F[j] | (bias << 13) | (rs.y << 26);
+            e.y = rs.x;
+        }
+        etab[p][64 * j + lane] = e;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // -- pass 2: rows from the last to the first ----------------------------------------------------------
+    uint32_t nwords = 0;
+    if (nsym > 1) {
+        uint16_t* out = reinterpret_cast<uint16_t*>(slot + g.slot_hdr + (size_t)p * g.slot_plane);
+        uint32_t x = RANS_L;
+        constexpr int RB = 8;
+        for (uint32_t rb = ((rows + RB - 1) / RB) * RB; rb > 0; rb -= RB) {
+            uint32_t sym[RB];
+            uint2 e[RB];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const uint32_t r = rb - 1 - k;
+                const uint32_t i = r * 64u + lane;
+                sym[k] = 0xFFFFFFFFu;
+                if (r < rows && i < n) {
+                    const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
+                                            : elem_offset(g, b, i);
+                    sym[k] = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++) e[k] = etab[p][sym[k] & 255u];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const bool act = sym[k] != 0xFFFFFFFFu;
+                const uint32_t f = e[k].x & 0x1FFFu;
+                const bool emit = act && x >= (f << 19);
+                const uint64_t em = __ballot(emit);
+                if (emit) {
+                    out[nwords + rank_below(em)] = (uint16_t)(x & 0xFFFFu);
+                    x >>= 16;
+                }
+                nwords += (uint32_t)__popcll(em);
+                if (act) {
+                    const uint32_t q = __umulhi(x, e[k].y) >> (e[k].x >> 26);
+                    x = x + ((e[k].x >> 13) & 0x1FFFu) + q * (RANS_M - f);
+                }
+            }
+        }
+        out[nwords + 2 * lane] = (uint16_t)(x & 0xFFFFu);       // low word, high word per lane
+        out[nwords + 2 * lane + 1] = (uint16_t)(x >> 16);
+        nwords += 128;
+    }
+    if (lane == 0) {
+        reinterpret_cast<uint32_t*>(slot + 8)[p] = nwords;
+        plane_bytes[p] = 32u + 2u * nsym + 2u * nwords;
+        if (p == 0) {
+            slot[0] = 'E';
+            slot[1] = 'X';
+            slot[2] = 1;
+            slot[3] = (uint8_t)TS;
+            reinterpret_cast<uint32_t*>(slot)[1] = n;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 8u + 4u * TS;
+#pragma unroll
+        for (int q = 0; q < TS; q++) total += plane_bytes[q];
+        sizes[c] = total;
+    }
+}
+
+// offsets[c] = sum of the 16-byte-aligned sizes of the chunks before c; offsets[nchunks] = container
+// bytes; totals = { sum of the exact sizes, container bytes }.  One workgroup.
+__global__ __launch_bounds__(1024) void rans_scan_kernel(const uint32_t* __restrict__ sizes, int nchunks,
+                                                         unsigned long long* __restrict__ offsets,
+                                                         unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long part[1024], exact[1024];
+    const int t = threadIdx.x;
+    const int per = (nchunks + 1023) / 1024;
+    const int c0 = min(t * per, nchunks), c1 = min(c0 + per, nchunks);
+    unsigned long long a = 0, e = 0;
+    for (int c = c0; c < c1; c++) {
+        a += ((unsigned long long)sizes[c] + 15ull) & ~15ull;
+        e += sizes[c];
+    }
+    part[t] = a;
+    exact[t] = e;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long run = 0, ex = 0;
+        for (int i = 0; i < 1024; i++) {
+            const unsigned long long v = part[i];
+            part[i] = run;
+            run += v;
+            ex += exact[i];
+        }
+        offsets[nchunks] = run;
+        totals[0] = ex;
+        totals[1] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[t];
+    for (int c = c0; c < c1; c++) {
+        offsets[c] = run;
+        run += ((unsigned long long)sizes[c] + 15ull) & ~15ull;
+    }
+}
+
+// slot -> packed stream at out + offsets[c]; all pieces are whole 16-bit words.
+template <int TS>
+__global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t* __restrict__ slots, CodecGeom g,
+                                                        const unsigned long long* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ sizes,
+                                                        uint8_t* __restrict__ out) {
+    const int c = blockIdx.x;
+    const uint8_t* slot = slots + (size_t)c * g.slot_bytes;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out + offsets[c]);
+    const uint32_t* nwords = reinterpret_cast<const uint32_t*>(slot + 8);
+    uint32_t pos = 0;
+    {   // header
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(slot);
+        for (uint32_t i = threadIdx.x; i < 4u + 2u * TS; i += 256) dst[i] = src[i];
+        pos = 4u + 2u * TS;
+    }
+    for (int p = 0; p < TS; p++) {   // tables
+        const uint8_t* tab = slot + 8 + 4 * TS + p * HDR_TABLE;
+        const uint64_t* bm = reinterpret_cast<const uint64_t*>(tab);
+        const uint32_t nsym = (uint32_t)(__popcll(bm[0]) + __popcll(bm[1]) + __popcll(bm[2]) + __popcll(bm[3]));
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(tab);
+        for (uint32_t i = threadIdx.x; i < 16u + nsym; i += 256) dst[pos + i] = src[i];
+        pos += 16u + nsym;
+    }
+    for (int p = 0; p < TS; p++) {   // streams
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(slot + g.slot_hdr + (size_t)p * g.slot_plane);
+        const uint32_t nw = nwords[p];
+        for (uint32_t i = threadIdx.x; i < nw; i += 256) dst[pos + i] = src[i];
+        pos += nw;
+    }
+    // zero the alignment padding so that the container is deterministic
+    const uint32_t sz = sizes[c], padded = (sz + 15u) & ~15u;
+    for (uint32_t i = sz / 2 + threadIdx.x; i < padded / 2; i += 256) dst[i] = 0;
+}
+
+// ---- decode: one workgroup per chunk, wave p decodes byte plane p -----------------------------------------
+// status[0] is set to a non-zero code by any chunk whose stream is malformed (that chunk is skipped).
+template <int TS>
+__global__ __launch_bounds__(64 * TS) void rans_decode_kernel(const uint8_t* __restrict__ in,
+                                                             const unsigned long long* __restrict__ offsets,
+                                                             CodecGeom g, void* __restrict__ vol,
+                                                             uint32_t* __restrict__ status) {
+    __shared__ uint8_t slot2sym[TS][RANS_M];
+    __shared__ uint32_t dtab[TS][256];     // F | C << 16
+    const int c = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const int p = threadIdx.x >> 6;
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t n = b.n;
+    const uint32_t rows = (n + 63u) >> 6;
+    const bool fast = (b.ex == 64);
+    const uint8_t* s0 = in + offsets[c];
+    const size_t avail = (size_t)(offsets[c + 1] - offsets[c]);
+
+    // header (uniform)
+    bool ok = avail >= 8u + 4u * TS && s0[0] == 'E' && s0[1] == 'X' && s0[2] == 1 && s0[3] == TS &&
+              reinterpret_cast<const uint32_t*>(s0)[1] == n;
+    uint32_t my_nwords = 0, my_nsym = 0;
+    size_t tab_off = 8 + 4 * TS, my_tab = 0, words_before = 0, total_words = 0;
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < TS; q++) {
+            const uint32_t nw = reinterpret_cast<const uint32_t*>(s0 + 8)[q];
+            if (tab_off + 32 > avail) {
+                ok = false;
+                break;
+            }
+            uint32_t ns = 0;
+            for (int k = 0; k < 16; k++) ns += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(s0 + tab_off)[k]);
+            if (q == p) {
+                my_nwords = nw;
+                my_nsym = ns;
+                my_tab = tab_off;
+            }
+            if (q < p) words_before += nw;
+            total_words += nw;
+            tab_off += 32 + 2 * (size_t)ns;
+        }
+    }
+    if (ok && tab_off + 2 * total_words > avail) ok = false;
+    if (ok && my_nsym > 1 && my_nwords < 128) ok = false;
+    if (ok && n > 0 && my_nsym == 0) ok = false;
+    // every wave of the chunk reaches the same verdict on the shared fields; a wave whose own plane
+    // is malformed only flags the chunk
+    if (!ok) {
+        if (lane == 0) atomicOr(status, 1u);
+        return;
+    }
+    if (n == 0) return;
+
+    // frequencies of this plane: lane l owns symbols 64 j + l
+    const uint16_t* bm16 = reinterpret_cast<const uint16_t*>(s0 + my_tab);
+    const uint16_t* fl = reinterpret_cast<const uint16_t*>(s0 + my_tab + 32);
+    uint32_t F[4], C[4], seen = 0, cum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t pm = (uint64_t)bm16[4 * j] | ((uint64_t)bm16[4 * j + 1] << 16) |
+                            ((uint64_t)bm16[4 * j + 2] << 32) | ((uint64_t)bm16[4 * j + 3] << 48);
+        F[j] = ((pm >> lane) & 1ull) ? fl[seen + rank_below(pm)] : 0u;
+        seen += (uint32_t)__popcll(pm);
+        C[j] = cum + wave_excl_scan(F[j], lane);
+        cum += wave_sum(F[j]);
+    }
+    if (cum != RANS_M) {
+        if (lane == 0) atomicOr(status, 2u);
+        return;
+    }
+
+    uint8_t* dst = static_cast<uint8_t*>(vol);
+    if (my_nsym == 1) {          // constant plane
+        uint32_t only = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) only = max(only, F[j] ? 64u * j + lane : 0u);
+        only = wave_max(only);
+        for (uint32_t r = 0; r < rows; r++) {
+            const uint32_t i = r * 64u + lane;
+            if (i < n) {
+                const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
+                                        : elem_offset(g, b, i);
+                dst[(b.base + off) * TS + p] = (uint8_t)only;
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        dtab[p][64 * j + lane] = F[j] | (C[j] << 16);
+        // slots [C, C + F) of symbol 64 j + l: filled cooperatively below
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < 256; s++) {
+        const uint32_t e = dtab[p][s];
+        const uint32_t f = e & 0xFFFFu, cs = e >> 16;
+        for (uint32_t t = lane; t < f; t += 64) slot2sym[p][cs + t] = (uint8_t)s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const uint16_t* words = reinterpret_cast<const uint16_t*>(s0 + tab_off) + words_before;
+    uint32_t cursor = my_nwords - 128;
+    uint32_t x = (uint32_t)words[cursor + 2 * lane] | ((uint32_t)words[cursor + 2 * lane + 1] << 16);
+    bool bad = false;
+    for (uint32_t r = 0; r < rows; r++) {
+        const uint32_t i = r * 64u + lane;
+        const bool act = i < n;
+        bool need = false;
+        if (act) {
+            const uint32_t slot = x & (RANS_M - 1u);
+            const uint32_t s = slot2sym[p][slot];
+            const uint32_t e = dtab[p][s];
+            x = (e & 0xFFFFu) * (x >> RANS_BITS) + slot - (e >> 16);
+            need = x < RANS_L;
+            const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
+                                    : elem_offset(g, b, i);
+            dst[(b.base + off) * TS + p] = (uint8_t)s;
+        }
+        const uint64_t nm = __ballot(need);
+        const uint32_t k = (uint32_t)__popcll(nm);
+        if (k > cursor) {
+            bad = true;
+            break;
+        }
+        cursor -= k;
+        if (need) x = (x << 16) | words[cursor + rank_below(nm)];
+    }
+    if (bad && lane == 0) atomicOr(status, 4u);
+}
+
+// in-place inverse of the int32 -> unsigned map of the 4-byte element kind
+__global__ __launch_bounds__(256) void unzigzag_kernel(uint32_t* __restrict__ v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint32_t u = v[i];
+        v[i] = (u >> 1) ^ (0u - (u & 1u));
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+size_t codec_chunk_bound(size_t n, int ts) {
+    return 8 + 4 * (size_t)ts + (size_t)ts * HDR_TABLE + (size_t)ts * 2 * (n + 128);
+}
+
+int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g) {
+    if (ts != 2 && ts != 4) return -1;
+    if (nz < 1 || ny < 1 || nx < 1 || cz < 1 || cy < 1 || cx < 1) return -1;
+    cz = cz < nz ? cz : nz;
+    cy = cy < ny ? cy : ny;
+    cx = cx < nx ? cx : nx;
+    const unsigned long long cn = (unsigned long long)cz * cy * cx;
+    if (cn > (1ull << 28)) return -1;            // rows * 64 must stay inside 32 bits
+    g.ts = ts;
+    g.nz = nz; g.ny = ny; g.nx = nx;
+    g.cz = cz; g.cy = cy; g.cx = cx;
+    g.gz = (nz + cz - 1) / cz;
+    g.gy = (ny + cy - 1) / cy;
+    g.gx = (nx + cx - 1) / cx;
+    const unsigned long long nchunks = (unsigned long long)g.gz * g.gy * g.gx;
+    if (nchunks > 0x7FFFFFFFull) return -1;
+    g.nchunks = (int)nchunks;
+    g.slot_hdr = ((size_t)(8 + 4 * ts + ts * HDR_TABLE) + 15) & ~(size_t)15;
+    g.slot_plane = ((size_t)2 * ((size_t)cn + 128) + 15) & ~(size_t)15;
+    g.slot_bytes = g.slot_hdr + (size_t)ts * g.slot_plane;
+    return 0;
+}
+
+size_t codec_volume_bound(const CodecGeom& g) {
+    // every chunk at its own worst case, 16-byte aligned
+    size_t total = 0;
+    for (int bz = 0; bz < g.gz; bz++) {
+        const size_t ez = (size_t)(g.cz < g.nz - bz * g.cz ? g.cz : g.nz - bz * g.cz);
+        for (int by = 0; by < g.gy; by++) {
+            const size_t ey = (size_t)(g.cy < g.ny - by * g.cy ? g.cy : g.ny - by * g.cy);
+            const int full = g.nx / g.cx, rem = g.nx - full * g.cx;
+            total += (size_t)full * ((codec_chunk_bound(ez * ey * (size_t)g.cx, g.ts) + 15) & ~(size_t)15);
+            if (rem) total += (codec_chunk_bound(ez * ey * (size_t)rem, g.ts) + 15) & ~(size_t)15;
+        }
+    }
+    return total;
+}
+
+void codec_fill_rcp_table(uint32_t* tab /* [4097][2] */) {
+    tab[0] = tab[1] = 0;
+    for (uint32_t f = 1; f <= RANS_M; f++) {
+        if (f == 1) {
+            tab[2] = 0xFFFFFFFFu;    // q = x - 1, bias carries the + M - 1 (ryg's freq = 1 form)
+            tab[3] = 0;
+            continue;
+        }
+        uint32_t shift = 0;
+        while (f > (1u << shift)) shift++;
+        tab[2 * f] = (uint32_t)((((unsigned long long)1 << (shift + 31)) + f - 1) / f);
+        tab[2 * f + 1] = shift - 1;
+    }
+}
+
+hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
+                              uint32_t* sizes, unsigned long long* offsets, unsigned long long* totals,
+                              uint8_t* out, hipStream_t s) {
+    const uint2* rt = reinterpret_cast<const uint2*>(rcp_tab);
+    if (g.ts == 2)
+        hipLaunchKernelGGL(rans_encode_kernel<2>, dim3((unsigned)g.nchunks), dim3(128), 0, s, vol, g, rt,
+                           slots, sizes);
+    else
+        hipLaunchKernelGGL(rans_encode_kernel<4>, dim3((unsigned)g.nchunks), dim3(256), 0, s, vol, g, rt,
+                           slots, sizes);
+    hipLaunchKernelGGL(rans_scan_kernel, dim3(1), dim3(1024), 0, s, sizes, g.nchunks, offsets, totals);
+    if (out) {
+        if (g.ts == 2)
+            hipLaunchKernelGGL(rans_pack_kernel<2>, dim3((unsigned)g.nchunks), dim3(256), 0, s, slots, g,
+                               offsets, sizes, out);
+        else
+            hipLaunchKernelGGL(rans_pack_kernel<4>, dim3((unsigned)g.nchunks), dim3(256), 0, s, slots, g,
+                               offsets, sizes, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rans_decode(const uint8_t* in, const unsigned long long* offsets, const CodecGeom& g,
+                              void* vol, uint32_t* status, hipStream_t s) {
+    if (g.ts == 2) {
+        hipLaunchKernelGGL(rans_decode_kernel<2>, dim3((unsigned)g.nchunks), dim3(128), 0, s, in, offsets, g,
+                           vol, status);
+    } else {
+        hipLaunchKernelGGL(rans_decode_kernel<4>, dim3((unsigned)g.nchunks), dim3(256), 0, s, in, offsets, g,
+                           vol, status);
+        const size_t n = (size_t)g.nz * g.ny * g.nx;
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+        hipLaunchKernelGGL(unzigzag_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint32_t*>(vol), n);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace exabm4d

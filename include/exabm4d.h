@@ -17,6 +17,7 @@
  *   estimate_offset (np.percentile)       machine_learning/transforms.py:414-438
  *   ssim3D, compute_mae, compute_lmax     utils/img_util.py:953-1050
  *   evaluate_example and its parts        machine_learning/metrics.py:306-424
+ *   compute_cratio's codec.encode loop    utils/img_util.py:401-441 (codec: evaluate.py:40)
  *
  * Conventions
  *   - extern "C", plain pointers and sizes, POD structs whose first field is their own sizeof
@@ -250,6 +251,34 @@ int exabm4d_dctq_inverse_dev(exabm4d_ctx* ctx, const int32_t* idx, int nz, int n
  * for -32767 <= v <= 32767, bin 0 (the escape symbol) for everything else.  hist_host[65536]. */
 int exabm4d_i32_symbol_histogram_dev(exabm4d_ctx* ctx, const int32_t* idx, size_t n,
                                      uint64_t* hist_host);
+
+/* Chunk entropy coder (BASELINE.json config 5 "entropy encode").  Replaces the
+ * arithmetic behind `len(codec.encode(chunk))` in compute_cratio(img, codec, patch_shape=(64,64,64))
+ * (utils/img_util.py:401-441: C-order chunks, edge chunks truncated) with the codec the reference
+ * builds at evaluate.py:40 / scripts/evaluate_bm4dnet.py:140 -- Blosc(zstd, SHUFFLE): the same
+ * byte shuffle (one plane per byte position of the element) in front of an entropy stage.  zstd is
+ * third-party and absent, so the entropy stage is this repo's: static order-0 rANS per byte plane,
+ * 64 interleaved states (the lanes of one wave), EXAC v1 stream (oracle/exac_codec.c states the
+ * format; bytes are bit-identical to it).  typesize 2 = uint16 volumes, 4 = int32 quantisation
+ * indices (exabm4d_dctq_forward_dev), mapped to unsigned by (v << 1) ^ (v >> 31).
+ *
+ * One call codes every chunk of a volume.  out (device, may be NULL: sizes only) receives the chunk
+ * streams back to back, each starting at a multiple of 16 bytes (padding zeroed); out_capacity must
+ * be >= exabm4d_codec_volume_bound().  offsets_dev[nchunks + 1] (device; may be NULL when out is
+ * NULL) receives the start of every chunk's stream and the container length; sizes_dev[nchunks]
+ * (device, may be NULL) the exact stream lengths, i.e. len(codec.encode(chunk)); totals_host[2]
+ * (host, may be NULL; non-NULL makes the call synchronise) = { sum of the exact lengths, container
+ * bytes }.  Chunks are numbered in (z, y, x) raster order. */
+size_t exabm4d_codec_chunk_bound(size_t n_elems, int typesize);
+size_t exabm4d_codec_volume_bound(int typesize, int nz, int ny, int nx, int cz, int cy, int cx);
+int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int nz, int ny, int nx,
+                             int cz, int cy, int cx, uint8_t* out, size_t out_capacity,
+                             uint64_t* offsets_dev, uint32_t* sizes_dev, uint64_t* totals_host);
+/* Inverse: in + offsets_dev as produced above (or assembled by a host from stored streams) ->
+ * vol[nz][ny][nx] of `typesize`-byte elements.  Synchronises; a malformed stream (bad magic,
+ * wrong element count, truncated tables or words) gives EXABM4D_ERR_INVALID. */
+int exabm4d_codec_decode_dev(exabm4d_ctx* ctx, const uint8_t* in, const uint64_t* offsets_dev,
+                             int typesize, int nz, int ny, int nx, int cz, int cy, int cx, void* vol);
 
 /* ---- background offset + quality metrics on device (SURVEY.md section 8 "next" row f-4) --------- */
 /* Element types of the metric entry points. */

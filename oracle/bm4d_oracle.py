@@ -21,8 +21,8 @@ KEY_EMPTY = 0xFFFFFFFF
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "exabm4d_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("exabm4d_oracle.c", "exac_codec.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(map(os.path.getmtime, srcs)):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _SO
 
