@@ -43,6 +43,41 @@ __device__ __forceinline__ size_t elem_offset(const CodecGeom& g, const ChunkBox
     return ((size_t)z * g.ny + y) * g.nx + x;
 }
 
+// Rows of 64 consecutive chunk elements when the chunk's x extent is a multiple of 64: a row is
+// then 64 consecutive elements of one x-row of the volume, and walking the rows forwards or
+// backwards only needs three wave-uniform counters (no per-lane division).
+struct RowCursor {
+    uint32_t xr, y, z;      // 64-element segment inside the x-row, y, z of the current row
+    uint32_t rpx, ey;       // segments per x-row, chunk extent along y
+    __device__ __forceinline__ void seek(uint32_t r) {
+        xr = r % rpx;
+        const uint32_t t = r / rpx;
+        y = t % ey;
+        z = t / ey;
+    }
+    __device__ __forceinline__ void next() {
+        if (++xr == rpx) {
+            xr = 0;
+            if (++y == ey) {
+                y = 0;
+                z++;
+            }
+        }
+    }
+    __device__ __forceinline__ void prev() {
+        if (xr-- == 0) {
+            xr = rpx - 1;
+            if (y-- == 0) {
+                y = ey - 1;
+                z--;
+            }
+        }
+    }
+    __device__ __forceinline__ size_t offset(const CodecGeom& g) const {
+        return ((size_t)z * g.ny + y) * g.nx + xr * 64u;
+    }
+};
+
 template <int TS>
 __device__ __forceinline__ uint32_t load_bits(const void* vol, size_t e) {
     if (TS == 2) return static_cast<const uint16_t*>(vol)[e];
@@ -137,7 +172,10 @@ __global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __rest
     const ChunkBox b = chunk_box(g, c);
     const uint32_t n = b.n;
     const uint32_t rows = (n + 63u) >> 6;
-    const bool fast = (b.ex == 64);       // a row of 64 elements is one x-row of the chunk
+    const bool fast = (b.ex & 63) == 0;   // a row of 64 elements lies inside one x-row of the volume
+    RowCursor rc;
+    rc.rpx = (uint32_t)b.ex >> 6;
+    rc.ey = (uint32_t)b.ey;
     uint8_t* slot = slots + (size_t)c * g.slot_bytes;
 
 #pragma unroll
@@ -146,15 +184,16 @@ __global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __rest
     __builtin_amdgcn_wave_barrier();
 
     // -- pass 1: byte histogram of this wave's plane -------------------------------------------------
+    rc.xr = rc.y = rc.z = 0;
     for (uint32_t r = 0; r < rows; r++) {
         const uint32_t i = r * 64u + lane;
         const bool act = i < n;
         uint32_t s = 0;
         if (act) {
-            const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
-                                    : elem_offset(g, b, i);
+            const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
             s = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
         }
+        if (fast) rc.next();
         const uint64_t am = __ballot(act);
         const uint32_t s0 = __builtin_amdgcn_readfirstlane(s);
         const uint64_t same = __ballot(act && s == s0);
@@ -205,6 +244,7 @@ __global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __rest
         uint16_t* out = reinterpret_cast<uint16_t*>(slot + g.slot_hdr + (size_t)p * g.slot_plane);
         uint32_t x = RANS_L;
         constexpr int RB = 8;
+        if (fast && rows) rc.seek(rows - 1);
         for (uint32_t rb = ((rows + RB - 1) / RB) * RB; rb > 0; rb -= RB) {
             uint32_t sym[RB];
             uint2 e[RB];
@@ -213,10 +253,12 @@ __global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __rest
                 const uint32_t r = rb - 1 - k;
                 const uint32_t i = r * 64u + lane;
                 sym[k] = 0xFFFFFFFFu;
-                if (r < rows && i < n) {
-                    const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
-                                            : elem_offset(g, b, i);
-                    sym[k] = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
+                if (r < rows) {
+                    if (i < n) {
+                        const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
+                        sym[k] = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
+                    }
+                    if (fast) rc.prev();
                 }
             }
 #pragma unroll
@@ -349,7 +391,11 @@ __global__ __launch_bounds__(64 * TS) void rans_decode_kernel(const uint8_t* __r
     const ChunkBox b = chunk_box(g, c);
     const uint32_t n = b.n;
     const uint32_t rows = (n + 63u) >> 6;
-    const bool fast = (b.ex == 64);
+    const bool fast = (b.ex & 63) == 0;
+    RowCursor rc;
+    rc.rpx = (uint32_t)b.ex >> 6;
+    rc.ey = (uint32_t)b.ey;
+    rc.xr = rc.y = rc.z = 0;
     const uint8_t* s0 = in + offsets[c];
     const size_t avail = (size_t)(offsets[c + 1] - offsets[c]);
 
@@ -416,10 +462,10 @@ __global__ __launch_bounds__(64 * TS) void rans_decode_kernel(const uint8_t* __r
         for (uint32_t r = 0; r < rows; r++) {
             const uint32_t i = r * 64u + lane;
             if (i < n) {
-                const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
-                                        : elem_offset(g, b, i);
+                const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
                 dst[(b.base + off) * TS + p] = (uint8_t)only;
             }
+            if (fast) rc.next();
         }
         return;
     }
@@ -453,10 +499,10 @@ __global__ __launch_bounds__(64 * TS) void rans_decode_kernel(const uint8_t* __r
             const uint32_t e = dtab[p][s];
             x = (e & 0xFFFFu) * (x >> RANS_BITS) + slot - (e >> 16);
             need = x < RANS_L;
-            const size_t off = fast ? ((size_t)(r / (uint32_t)b.ey) * g.ny + (r % (uint32_t)b.ey)) * g.nx + lane
-                                    : elem_offset(g, b, i);
+            const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
             dst[(b.base + off) * TS + p] = (uint8_t)s;
         }
+        if (fast) rc.next();
         const uint64_t nm = __ballot(need);
         const uint32_t k = (uint32_t)__popcll(nm);
         if (k > cursor) {

@@ -4,11 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
 
 Step  = one pass of the hot path over one synthetic uint16 volume that is already resident in
-        HBM: uint16 counts -> fp32 - offset -> block matching -> hard-threshold stage -> basic
-        estimate -> block matching -> Wiener stage -> normalise -> + offset -> clip -> rint ->
-        uint16, through the C-ABI entry exabm4d_denoise_u16_dev (include/exabm4d.h).
-Metric = BASELINE.json's "denoised+encoded voxels/s on 1024^3 uint16" (the reference's only
-        quantiser is the rint/uint16 cast; its entropy coder is third-party Blosc, out of scope).
+        HBM, all through the C-ABI (include/exabm4d.h):
+        (1) exabm4d_denoise_u16_dev: uint16 counts -> fp32 - offset -> block matching ->
+            hard-threshold stage -> basic estimate -> block matching -> Wiener stage -> normalise
+            -> + offset -> clip -> rint -> uint16;
+        (2) exabm4d_codec_encode_dev: the denoised volume coded losslessly in 64^3 chunks (byte
+            shuffle + order-0 rANS per plane, packed byte streams in HBM) -- the device
+            counterpart of the reference's compute_cratio / write_zarr codec pass
+            (utils/img_util.py:401-441, :935-950);
+        (3) BASELINE config 5's lossy leg: exabm4d_dctq_forward_dev (8^3 block DCT, step Q_STEP)
+            and exabm4d_codec_encode_dev on the int32 indices.
+Metric = BASELINE.json's "denoised+encoded voxels/s on 1024^3 uint16".
 N > 1 = one process per GPU (torch.distributed / RCCL for the barrier and the max over ranks);
         every rank denoises its own volume, no data-path collective ("weak" scaling).
 
@@ -31,6 +37,8 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+Q_STEP = 8.0      # quantiser step of the timed config-5 leg (tools/rd_sweep.py sweeps it)
+CHUNK = (64, 64, 64)  # reference compute_cratio patch_shape, utils/img_util.py:401
 SIGMA = 24.0      # reference scripts/precompute.py:284
 OFFSET = 37.0     # reference scripts/evaluate_bm4dnet.py:207
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -45,6 +53,10 @@ ALGO_BYTES_PER_VOXEL = {
     "blockmatch_wie": 4 + 1,
     "stage_wie": 1 + 4 + 4 + 8,
     "normalize_out": 8 + 2,
+    # encode legs: volume / indices read once + the packed streams written (measured per run)
+    "encode_u16": 2,
+    "dct_quantise": 2 + 4,
+    "encode_idx": 4,
 }
 
 
@@ -199,6 +211,8 @@ def main():
                          "data-path collective (default); 'slabs' = one (N*size) x size x size "
                          "volume split into z-slabs with an RCCL halo exchange of the basic "
                          "estimate between the two stages (distributed.py)")
+    ap.add_argument("--no-encode", action="store_true",
+                    help="time the denoiser alone (the metric's step includes the encode legs)")
     ap.add_argument("--cpu-sample", type=int, default=128,
                     help="edge of the CPU-baseline sample (0 disables the baseline)")
     args = ap.parse_args()
@@ -245,8 +259,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # encode legs: packed streams, offsets and sizes stay in HBM
+    nchunks = int(np.prod([-(-n // c) for n, c in zip(shape, CHUNK)]))
+    cap16 = _native.codec_volume_bound(2, shape, CHUNK)
+    d_enc16, d_off16, d_sz16 = ctx.alloc(cap16), ctx.alloc(8 * (nchunks + 1)), ctx.alloc(4 * nchunks)
+    nblk = int(np.prod([-(-n // 8) for n in shape]))
+    idx_shape, idx_chunk = (nblk, 8, 64), (512, 8, 64)       # 2^18 consecutive indices per chunk
+    nchunks_i = -(-nblk // 512)
+    cap32 = _native.codec_volume_bound(4, idx_shape, idx_chunk)
+    d_idx = ctx.alloc(4 * nblk * 512)
+    d_enc32, d_off32, d_sz32 = ctx.alloc(cap32), ctx.alloc(8 * (nchunks_i + 1)), ctx.alloc(4 * nchunks_i)
+    ev = [ctx.event() for _ in range(4)]
+
     def step():
         ctx.denoise_u16(d_in, d_out, shape, SIGMA, OFFSET, params=params, stages=args.stages)
+        if args.no_encode:
+            return
+        ctx.record(ev[0])
+        ctx.codec_encode(d_out, 2, shape, CHUNK, out=d_enc16, out_capacity=cap16, offsets=d_off16,
+                         sizes=d_sz16, totals=False)
+        ctx.record(ev[1])
+        ctx.dctq_forward(d_out, shape, Q_STEP, d_idx)
+        ctx.record(ev[2])
+        ctx.codec_encode(d_idx, 4, idx_shape, idx_chunk, out=d_enc32, out_capacity=cap32,
+                         offsets=d_off32, sizes=d_sz32, totals=False)
+        ctx.record(ev[3])
 
     ctx.set_option("profile", 1)
     for _ in range(args.warmup):
@@ -258,6 +295,9 @@ def main():
         step()
         for k, v in ctx.profile_read().items():      # waits for this step's events only
             phase_ms[k] = phase_ms.get(k, 0.0) + v
+        if not args.no_encode:
+            for i, k in enumerate(("encode_u16", "dct_quantise", "encode_idx")):
+                phase_ms[k] = phase_ms.get(k, 0.0) + ctx.elapsed_ms(ev[i], ev[i + 1])
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -271,6 +311,21 @@ def main():
     sl = (slice(0, min(64, shape[0])),)
     resid = out[sl].astype(np.float32) - vol[sl].astype(np.float32)
     resid_std = float(resid.std())
+    encoded = None
+    if not args.no_encode:
+        sz16 = d_sz16.download((nchunks,), np.uint32).astype(np.uint64)
+        sz32 = d_sz32.download((nchunks_i,), np.uint32).astype(np.uint64)
+        # the same coder on the noisy input, outside the timed region: the reference reports
+        # cratio(raw) next to cratio(denoised) (scripts/evaluate_bm4dnet.py:141-145)
+        raw_bytes, _ = ctx.codec_encode(d_in, 2, shape, CHUNK)
+        encoded = {
+            "codec": "EXAC v1: byte shuffle + order-0 rANS per plane, 64^3 chunks (DESIGN.md 3.11)",
+            "cratio_denoised": round(2.0 * nvox / float(sz16.sum()), 2),
+            "cratio_raw": round(2.0 * nvox / float(raw_bytes), 2),
+            "lossless_bytes": int(sz16.sum()),
+            "dct_q": Q_STEP,
+            "dct_bits_per_voxel": 8.0 * float(sz32.sum()) / nvox,
+        }
 
     if rank == 0:
         phase_avg = {k: v / max(args.steps, 1) for k, v in phase_ms.items() if v > 0}
@@ -298,6 +353,9 @@ def main():
                             f"{args.size}^3 uint16 volume per GPU, hard-threshold stage only",
                 "volume": list(shape),
                 "stages": args.stages,
+                "encode": "none" if args.no_encode else
+                          f"lossless EXAC of the denoised volume in 64^3 chunks + config-5 leg "
+                          f"(8^3 block DCT, q = {Q_STEP:g}, EXAC of the int32 indices)",
                 "sharding": "one independent volume per rank, no data-path collective",
             },
             "roofline": {
@@ -314,6 +372,8 @@ def main():
             "phase_ms": phase_avg,
             "residual_std": resid_std,
         }
+        if encoded is not None:
+            result["encoded"] = encoded
         if args.cpu_sample > 0 and world == 1:         # reported baseline: rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000)
         print(json.dumps(result), flush=True)

@@ -54,6 +54,7 @@ def test_committed_format_vectors():
     ((3, 5, 1000), (2, 5, 300)),           # rows that straddle chunk rows (generic addressing)
     ((1, 1, 5000), (1, 1, 4096)),
     ((128, 64, 64), (64, 64, 64)),
+    ((6, 10, 320), (4, 6, 128)),           # x extent a multiple of 64: row-cursor addressing
 ])
 def test_uint16_volumes_bit_identical_and_round_trip(shape, chunk):
     vol = denoised_like(shape, seed=sum(shape))
@@ -123,7 +124,7 @@ def test_compute_cratio_with_the_device_codec():
     assert got == img_util.compute_cratio(vol, Loop()) == round(vol.nbytes / packed, 2)
     assert got == img_util.compute_cratio(vol[None, None], codec)       # 5-D input like the reference
     assert got <= img_util.shuffled_entropy_cratio(vol)                  # never above the order-0 floor
-    assert got > 0.97 * img_util.shuffled_entropy_cratio(vol) and got > 4.0
+    assert got > 0.97 * img_util.shuffled_entropy_cratio(vol) and got > 3.5
 
 
 def test_errors():
