@@ -102,6 +102,8 @@ SIGNATURES = {
     "exabm4d_normalize_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F, _F]),
     "exabm4d_denoise_f32_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
+    "exabm4d_denoise_chunked_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, _F, _F, _PP,
+                                             _I]),
     "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
     "exabm4d_transform_forward_f32_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
@@ -331,6 +333,17 @@ class Context:
                                                   batch, float(sigma), float(offset),
                                                   ctypes.byref(p), int(stages)))
 
+    def denoise_chunked_u16(self, src, dst, shape, sigma, offset, chunk=256, halo=8, core=None,
+                            params=None, stages=2):
+        """Chunk-local mode: ``src`` [nz,ny,nx] uint16 on the device, ``dst`` receives the core
+        planes ``core = (zc0, zc1)`` (default: all planes)."""
+        p = params or default_params()
+        nz, ny, nx = shape
+        zc0, zc1 = (0, nz) if core is None else core
+        self._check(lib().exabm4d_denoise_chunked_u16_dev(
+            self.handle, _ptr(src), _ptr(dst), nz, ny, nx, int(zc0), int(zc1), int(chunk),
+            int(halo), float(sigma), float(offset), ctypes.byref(p), int(stages)))
+
     def denoise_f32_host(self, arr, sigma, params=None, stages=2, clip=None):
         """numpy fp32 [N,]Z,Y,X in -> new numpy array out (H2D, kernels, D2H, sync)."""
         p = params or default_params()
@@ -468,6 +481,27 @@ class Context:
 
 _contexts = {}
 _ctx_lock = threading.Lock()
+_hip_owner_pid = None        # pid of the process in which this module first created a context
+_forked_from_hip_parent = False
+
+
+def _after_fork_in_child():
+    """HIP state does not survive fork(): a child of a process that had already initialised HIP
+    (through this module or through torch) cannot use the GPU.  The reference's callers fork
+    workers BEFORE any of them touches BM4D (scripts/precompute.py:215-222), which works; the
+    other order must fail loudly instead of hanging in the driver."""
+    global _forked_from_hip_parent
+    torch_mod = __import__("sys").modules.get("torch")
+    torch_up = False
+    try:
+        torch_up = bool(torch_mod is not None and torch_mod.cuda.is_initialized())
+    except Exception:
+        pass
+    if _hip_owner_pid is not None or torch_up:
+        _forked_from_hip_parent = True
+
+
+os.register_at_fork(after_in_child=_after_fork_in_child)
 
 
 def context(device=None):
@@ -476,12 +510,20 @@ def context(device=None):
     A context inherited through fork() is never reused: HIP state does not survive fork."""
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
+    global _hip_owner_pid
+    if _forked_from_hip_parent:
+        raise NativeError(
+            "this process was fork()ed from a process that had already initialised HIP; the GPU "
+            "cannot be used here.  Fork the workers before the parent touches the GPU (as "
+            "scripts/precompute.py does), or start them with the 'spawn' method.")
     key = (os.getpid(), int(device))
     with _ctx_lock:
         ctx = _contexts.get(key)
         if ctx is None:
             ctx = Context(device)
             _contexts[key] = ctx
+            if _hip_owner_pid is None:
+                _hip_owner_pid = os.getpid()
     return ctx
 
 

@@ -108,3 +108,28 @@ def denoise_volume(vol_u16, sigma, offset=0.0, profile=None, stages=2, device=No
     finally:
         d_in.free()
         d_out.free()
+
+
+def denoise_chunked(vol_u16, sigma, offset=0.0, chunk=256, halo=8, profile=None, stages=2,
+                    device=None):
+    """Chunk-local mode of BASELINE.json config 4: the volume is tiled by ``chunk``^3 cores, every
+    core is read with ``halo`` voxels on each side (edge-replicated at the volume's faces) and
+    denoised in isolation -- independent units, like the reference's one-``bm4d``-call-per-patch
+    pool (scripts/precompute.py:215-228) -- and only the cores are written.  One batched device
+    call (``exabm4d_denoise_chunked_u16_dev``); uint16 in, uint16 out."""
+    vol = np.ascontiguousarray(vol_u16, dtype=np.uint16)
+    if vol.ndim != 3:
+        raise ValueError("denoise_chunked expects a 3-D uint16 volume")
+    prof = profile or BM4DProfile()
+    ctx = _native.context(device)
+    d_in = ctx.to_device(vol)
+    d_out = ctx.alloc(vol.nbytes)
+    try:
+        ctx.denoise_chunked_u16(d_in, d_out, vol.shape, float(sigma), float(offset),
+                                chunk=int(chunk), halo=int(halo), params=prof.native(),
+                                stages=int(stages))
+        ctx.sync()
+        return d_out.download(vol.shape, np.uint16)
+    finally:
+        d_in.free()
+        d_out.free()

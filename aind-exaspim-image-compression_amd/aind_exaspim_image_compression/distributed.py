@@ -47,10 +47,11 @@ class SlabPlan:
         return slice(self.lo, self.lo + (self.z1 - self.z0))
 
 
-def plan_slabs(nz, world, rank, halo=EXACT_HALO, align=4):
+def plan_slabs(nz, world, rank, halo=EXACT_HALO, align=4, halo_step=4):
     """Split ``nz`` planes into ``world`` contiguous slabs whose boundaries are multiples of
-    ``align``; every slab gets at least ``halo`` planes so that a halo never spans two ranks."""
-    if halo % align:
+    ``align``; every slab gets at least ``halo`` planes so that a halo never spans two ranks.
+    (Chunk-local mode: ``align`` = the chunk edge, so that no chunk straddles two ranks.)"""
+    if halo % halo_step:
         raise ValueError("halo must be a multiple of the grid step")
     units = nz // align
     if units < world:
@@ -63,34 +64,69 @@ def plan_slabs(nz, world, rank, halo=EXACT_HALO, align=4):
                     p1=min(nz, z1 + halo), halo=halo)
 
 
+class HaloExchange:
+    """An in-flight exchange of halo planes with the two slab neighbours: batched point-to-point
+    ``isend``/``irecv`` (RCCL over xGMI under the ``nccl`` backend).  ``wait()`` completes it and
+    copies the received planes into the halo of ``slab``.  Under the ``gloo`` backend (CPU tests,
+    single-GPU rehearsals) device tensors are staged through host memory."""
+
+    def __init__(self, slab, plan, dist=None, group=None):
+        import torch
+        self.slab, self.reqs, self.keep, self.ops = slab, [], [], []
+        if plan.world == 1:
+            return
+        if dist is None:
+            import torch.distributed as dist
+        stage = slab.is_cuda and dist.get_backend(group) == "gloo"
+
+        # 16-bit integer planes (raw counts) travel as bytes: RCCL has no int16 element type
+        as_bytes = slab.dtype not in (torch.float32, torch.float64, torch.float16, torch.bfloat16,
+                                      torch.int32, torch.int64, torch.uint8, torch.int8)
+
+        def out(t):
+            t = t.contiguous()
+            if as_bytes:
+                t = t.view(torch.uint8)
+            return t.cpu() if stage else t
+
+        def inbox(like):
+            shape = like.shape[:-1] + (like.shape[-1] * like.element_size(),) if as_bytes else like.shape
+            return torch.empty(shape, dtype=torch.uint8 if as_bytes else like.dtype,
+                               device="cpu" if stage else like.device)
+
+        ops = []
+        core = plan.core
+        n_own = plan.z1 - plan.z0
+        if plan.rank > 0:
+            recv = inbox(slab[:plan.lo])
+            ops += [dist.P2POp(dist.isend, out(slab[core.start:core.start + min(plan.halo, n_own)]),
+                               plan.rank - 1, group),
+                    dist.P2POp(dist.irecv, recv, plan.rank - 1, group)]
+            self.keep.append((slice(0, plan.lo), recv))
+        if plan.rank < plan.world - 1:
+            recv = inbox(slab[core.stop:])
+            ops += [dist.P2POp(dist.isend, out(slab[core.stop - min(plan.halo, n_own):core.stop]),
+                               plan.rank + 1, group),
+                    dist.P2POp(dist.irecv, recv, plan.rank + 1, group)]
+            self.keep.append((slice(core.stop, slab.shape[0]), recv))
+        self.ops = ops                                  # keeps the send buffers alive
+        self.reqs = dist.batch_isend_irecv(ops)
+
+    def wait(self):
+        for req in self.reqs:
+            req.wait()
+        for sl, buf in self.keep:
+            if buf.dtype != self.slab.dtype:
+                buf = buf.view(self.slab.dtype)
+            self.slab[sl].copy_(buf)
+        self.reqs, self.keep, self.ops = [], [], []
+        return self.slab
+
+
 def exchange_basic_halo(basic, plan, dist=None, group=None):
     """Fill the halo planes of ``basic`` (a torch tensor [p1-p0, ny, nx] on this rank's device)
     with the neighbours' owned planes, in place.  Blocking; all ranks must call it."""
-    if plan.world == 1:
-        return basic
-    import torch
-    if dist is None:
-        import torch.distributed as dist
-    ops, keep = [], []
-    core = plan.core
-    n_own = plan.z1 - plan.z0
-    if plan.rank > 0:
-        send = basic[core.start:core.start + min(plan.halo, n_own)].contiguous()
-        recv = torch.empty_like(basic[:plan.lo])
-        ops += [dist.P2POp(dist.isend, send, plan.rank - 1, group),
-                dist.P2POp(dist.irecv, recv, plan.rank - 1, group)]
-        keep.append((slice(0, plan.lo), recv))
-    if plan.rank < plan.world - 1:
-        send = basic[core.stop - min(plan.halo, n_own):core.stop].contiguous()
-        recv = torch.empty_like(basic[core.stop:])
-        ops += [dist.P2POp(dist.isend, send, plan.rank + 1, group),
-                dist.P2POp(dist.irecv, recv, plan.rank + 1, group)]
-        keep.append((slice(core.stop, basic.shape[0]), recv))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    for sl, buf in keep:
-        basic[sl].copy_(buf)
-    return basic
+    return HaloExchange(basic, plan, dist=dist, group=group).wait()
 
 
 def denoise_slab(noisy, plan, sigma, stage1, stage2, dist=None, group=None):
@@ -146,3 +182,65 @@ class SlabDenoiser:
 
     def stage2(self, noisy, basic):
         return self._run(basic, self.params.c_match_wie, noisy, basic)
+
+
+# ---- chunk-local mode across ranks (BASELINE.json config 4) -------------------------------------
+def plan_chunk_slabs(nz, world, rank, chunk=256, halo=8):
+    """z-slabs whose boundaries are multiples of ``chunk``: every rank owns whole layers of chunks
+    and needs only ``halo`` raw input planes from each neighbour."""
+    return plan_slabs(nz, world, rank, halo=halo, align=chunk, halo_step=1)
+
+
+def denoise_chunked_slab(raw, plan, run_chunks, chunk=256, dist=None, group=None):
+    """Chunk-local BM4D of this rank's slab.  ``raw``: [p1-p0, ny, nx] tensor of the raw counts (an
+    int16 view of the uint16 planes) whose owned planes are filled in; the neighbours' ``halo``
+    input planes are exchanged here, *while the chunk layers that do not touch them are already
+    being denoised*.  ``run_chunks(raw, (zc0, zc1)) -> core planes`` processes the chunk layers
+    whose cores are the local planes [zc0, zc1) (on the GPU: ``ChunkedSlabDenoiser.run``).  Returns
+    the owned planes."""
+    import torch
+    ex = HaloExchange(raw, plan, dist=dist, group=group)           # in flight from here on
+    core = plan.core
+    n_own = core.stop - core.start
+    lo_edge = core.start + (chunk if plan.lo else 0)               # first layer needs the lower halo
+    hi_edge = core.stop - (chunk if plan.hi else 0)
+    if lo_edge >= hi_edge:                                          # one or two layers: nothing to overlap
+        ex.wait()
+        return run_chunks(raw, (core.start, core.stop))
+    parts = {}
+    parts[lo_edge] = run_chunks(raw, (lo_edge, hi_edge))           # interior layers: own planes only
+    ex.wait()
+    if plan.lo:
+        parts[core.start] = run_chunks(raw, (core.start, lo_edge))
+    if plan.hi:
+        parts[hi_edge] = run_chunks(raw, (hi_edge, core.stop))
+    out = torch.cat([parts[k] for k in sorted(parts)], dim=0)
+    assert out.shape[0] == n_own
+    return out
+
+
+class ChunkedSlabDenoiser:
+    """``run_chunks`` of ``denoise_chunked_slab`` on one MI355X: one batched
+    ``exabm4d_denoise_chunked_u16_dev`` call per core range, torch tensors in and out."""
+
+    def __init__(self, sigma, offset, device, chunk=256, halo=8, params=None):
+        import torch
+        from aind_exaspim_image_compression import _native
+        self.torch = torch
+        self.sigma, self.offset, self.chunk, self.halo = float(sigma), float(offset), int(chunk), int(halo)
+        self.params = params or _native.default_params()
+        self.device = torch.device(device)
+        self.ctx = _native.context(self.device.index or 0)
+
+    def run(self, raw, core):
+        torch, ctx = self.torch, self.ctx
+        shape = tuple(int(s) for s in raw.shape)
+        out = torch.empty((core[1] - core[0],) + shape[1:], dtype=torch.int16, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            ctx.set_stream(stream.cuda_stream)
+            ctx.denoise_chunked_u16(raw, out, shape, self.sigma, self.offset, chunk=self.chunk,
+                                    halo=self.halo, core=core, params=self.params)
+            stream.synchronize()
+            ctx.reset_stream()
+        return out

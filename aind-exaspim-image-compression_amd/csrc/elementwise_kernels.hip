@@ -9,6 +9,8 @@
 // rounded to fp32 where numpy rounds it (host side, TfDev below) and every array operation is one
 // fp32 operation here (-ffp-contract=off; no fused multiply-add).  arcsinh / sinh are evaluated in
 // fp64 and rounded once.
+#include <algorithm>
+
 #include "exabm4d_kernels.h"
 
 namespace exabm4d {
@@ -321,6 +323,62 @@ hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz
     const int gz = (nz + cz - 1) / cz, gy = (ny + cy - 1) / cy, gx = (nx + cx - 1) / cx;
     hipLaunchKernelGGL(chunk_hist_kernel, dim3((unsigned)(gz * gy * gx)), dim3(EW_THREADS), 0, s,
                        vol, nz, ny, nx, cz, cy, cx, gy, gx, hist);
+    return hipGetLastError();
+}
+
+// ---- chunk-local mode (BASELINE config 4) ------------------------------
+// A batch of padded chunks: chunk (bz, by, bx) of a sub-grid has its core at (z0 + bz*cz, ...),
+// extent (ez, ey, ex), and is read with `halo` voxels on every side; indices beyond the buffer are
+// clamped (edge replication).  gather: u16 -> (float) - offset into [batch][pz][py][px];
+// scatter: the denoised padded chunks' cores -> + offset -> clip -> rint -> u16 into the output.
+__global__ __launch_bounds__(EW_THREADS) void chunk_gather_kernel(const uint16_t* __restrict__ in,
+                                                                  ChunkBatch cb, float offset,
+                                                                  float* __restrict__ out) {
+    const size_t pvox = (size_t)cb.pz * cb.py * cb.px;
+    const size_t total = pvox * (size_t)cb.count;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * EW_THREADS) {
+        const int b = (int)(i / pvox);
+        const size_t r = i - (size_t)b * pvox;
+        const int x = (int)(r % cb.px), y = (int)((r / cb.px) % cb.py), z = (int)(r / ((size_t)cb.px * cb.py));
+        const int c = cb.first + b;
+        const int bx = c % cb.sgx, by = (c / cb.sgx) % cb.sgy, bz = c / (cb.sgx * cb.sgy);
+        const int gz = min(max(cb.z0 + bz * cb.cz - cb.halo + z, 0), cb.nz - 1);
+        const int gy = min(max(cb.y0 + by * cb.cy - cb.halo + y, 0), cb.ny - 1);
+        const int gx = min(max(cb.x0 + bx * cb.cx - cb.halo + x, 0), cb.nx - 1);
+        out[i] = (float)in[((size_t)gz * cb.ny + gy) * cb.nx + gx] - offset;
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void chunk_scatter_kernel(const float* __restrict__ est,
+                                                                   ChunkBatch cb, float offset,
+                                                                   uint16_t* __restrict__ out) {
+    const size_t cvox = (size_t)cb.ez * cb.ey * cb.ex;
+    const size_t total = cvox * (size_t)cb.count;
+    const size_t pvox = (size_t)cb.pz * cb.py * cb.px;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * EW_THREADS) {
+        const int b = (int)(i / cvox);
+        const size_t r = i - (size_t)b * cvox;
+        const int x = (int)(r % cb.ex), y = (int)((r / cb.ex) % cb.ey), z = (int)(r / ((size_t)cb.ex * cb.ey));
+        const int c = cb.first + b;
+        const int bx = c % cb.sgx, by = (c / cb.sgx) % cb.sgy, bz = c / (cb.sgx * cb.sgy);
+        const float v = est[(size_t)b * pvox + ((size_t)(z + cb.halo) * cb.py + (y + cb.halo)) * cb.px + (x + cb.halo)];
+        const int oz = cb.z0 + bz * cb.cz + z - cb.out_z0, oy = cb.y0 + by * cb.cy + y, ox = cb.x0 + bx * cb.cx + x;
+        out[((size_t)oz * cb.ny + oy) * cb.nx + ox] = quantise_u16(v + offset, 65535.0f);
+    }
+}
+hipError_t launch_chunk_gather(const uint16_t* in, const ChunkBatch& cb, float offset, float* out,
+                               hipStream_t s) {
+    const size_t total = (size_t)cb.pz * cb.py * cb.px * (size_t)cb.count;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + EW_THREADS - 1) / EW_THREADS, 1u << 20);
+    hipLaunchKernelGGL(chunk_gather_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, in, cb, offset, out);
+    return hipGetLastError();
+}
+hipError_t launch_chunk_scatter(const float* est, const ChunkBatch& cb, float offset, uint16_t* out,
+                                hipStream_t s) {
+    const size_t total = (size_t)cb.ez * cb.ey * cb.ex * (size_t)cb.count;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + EW_THREADS - 1) / EW_THREADS, 1u << 20);
+    hipLaunchKernelGGL(chunk_scatter_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, est, cb, offset, out);
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 // exabm4d_api.hip -- the C-ABI of libexabm4d.so (include/exabm4d.h): context, scratch, tables,
 // argument checking and the launch sequences.  Host code only; kernels live in *_kernels.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,7 @@ struct exabm4d_ctx {
     int bm_guarded_copy = 0;   // exabm4d_set_option("bm_guarded_copy"): staged block matching on a guarded copy
     int stage_pairs = 1;       // exabm4d_set_option("stage_pairs"): two waves per group (HT stage)
     int profile = 0;           // exabm4d_set_option("profile")
+    int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
     std::string err;
@@ -279,6 +281,11 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     }
     if (std::strcmp(name, "stage_pairs") == 0) {
         ctx->stage_pairs = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "chunk_budget_mb") == 0) {
+        if (value < 1) return fail(ctx, EXABM4D_ERR_INVALID, "chunk_budget_mb must be >= 1");
+        ctx->chunk_budget_mb = value;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "profile") == 0) {
@@ -594,6 +601,82 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
     }
     return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
                         scratch, 1);
+}
+
+// Chunk-local mode: every chunk (core + halo, edge-replicated at the buffer's faces) is denoised in
+// isolation, batches of equally shaped chunks per pipeline run; only the cores are written.
+int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
+                                    int nx, int zc0, int zc1, int chunk, int halo, float sigma,
+                                    float offset, const exabm4d_params* p, int stages) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!(sigma > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma must be > 0");
+    if (stages != 1 && stages != 2) return fail(ctx, EXABM4D_ERR_INVALID, "stages must be 1 or 2");
+    if (nz < 1 || ny < 1 || nx < 1 || chunk < 1 || halo < 0 || halo > 64)
+        return fail(ctx, EXABM4D_ERR_INVALID, "chunked: sizes >= 1, chunk >= 1, 0 <= halo <= 64");
+    if (zc0 < 0 || zc1 > nz || zc0 >= zc1) return fail(ctx, EXABM4D_ERR_INVALID, "chunked: bad core plane range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = ensure_window(ctx, (double)p->kaiser_beta);
+    if (rc) return rc;
+    const int ext[3] = {zc1 - zc0, ny, nx};
+    // per axis: `full[a]` chunks of `chunk` voxels, then one of rem[a] voxels when rem[a] > 0
+    int full[3], rem[3];
+    for (int a = 0; a < 3; a++) {
+        full[a] = ext[a] / chunk;
+        rem[a] = ext[a] - full[a] * chunk;
+        const int smallest = rem[a] ? rem[a] : chunk;
+        if (smallest + 2 * halo < 8)
+            return fail(ctx, EXABM4D_ERR_INVALID, "chunked: a padded chunk would be thinner than one block (8)");
+    }
+    ctx->ev_used[EXABM4D_PHASE_COUNTS_FROM_U16] = false;
+    for (int cls = 0; cls < 8; cls++) {
+        // class bit a set: the ragged last chunk along axis a
+        int sg[3], e[3], o[3];
+        bool empty = false;
+        for (int a = 0; a < 3; a++) {
+            const bool ragged = (cls >> a) & 1;
+            sg[a] = ragged ? (rem[a] ? 1 : 0) : full[a];
+            e[a] = ragged ? rem[a] : chunk;
+            o[a] = ragged ? full[a] * chunk : 0;
+            if (sg[a] == 0) empty = true;
+        }
+        if (empty) continue;
+        ChunkBatch cb;
+        cb.nz = nz; cb.ny = ny; cb.nx = nx;
+        cb.z0 = zc0 + o[0]; cb.y0 = o[1]; cb.x0 = o[2];
+        cb.cz = cb.cy = cb.cx = chunk;
+        cb.ez = e[0]; cb.ey = e[1]; cb.ex = e[2];
+        cb.halo = halo;
+        cb.pz = e[0] + 2 * halo; cb.py = e[1] + 2 * halo; cb.px = e[2] + 2 * halo;
+        cb.sgy = sg[1]; cb.sgx = sg[2];
+        cb.out_z0 = zc0;
+        const long long nchunks = (long long)sg[0] * sg[1] * sg[2];
+        const size_t per = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, 1, stages) +
+                           align256((size_t)cb.pz * cb.py * cb.px * sizeof(float));
+        long long bmax = (long long)(((size_t)ctx->chunk_budget_mb << 20) / per);
+        if (bmax < 1) bmax = 1;
+        if (bmax > 65535) bmax = 65535;
+        for (long long first = 0; first < nchunks; first += bmax) {
+            const int count = (int)std::min<long long>(bmax, nchunks - first);
+            cb.first = (int)first;
+            cb.count = count;
+            VolGeom g;
+            rc = make_geom(ctx, cb.pz, cb.py, cb.px, count, g);
+            if (rc) return rc;
+            const size_t n = (size_t)g.nvox * (size_t)count;
+            const size_t base = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, count, stages);
+            rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+            if (rc) return rc;
+            char* scratch = static_cast<char*>(ctx->scratch);
+            float* vol = reinterpret_cast<float*>(scratch + base);
+            HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream));
+            rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f, scratch, 1);
+            if (rc) return rc;
+            HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
+        }
+    }
+    return EXABM4D_OK;
 }
 
 int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,

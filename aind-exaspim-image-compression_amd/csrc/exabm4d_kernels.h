@@ -67,6 +67,25 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
                                    const float* win1d, int overwrite, hipStream_t s);
 
+// ---- chunk-local mode (elementwise_kernels.hip) ------------------------------------------------------
+// One batch of equally shaped padded chunks out of a sub-grid of chunks (sgz x sgy x sgx chunks
+// whose first core starts at (z0, y0, x0)); chunk number first + b of the sub-grid is batch entry b.
+struct ChunkBatch {
+    int nz, ny, nx;          // input buffer
+    int z0, y0, x0;          // core origin of sub-grid chunk (0, 0, 0)
+    int cz, cy, cx;          // core pitch of the chunk grid
+    int ez, ey, ex;          // core extent of the chunks of this sub-grid (<= pitch)
+    int pz, py, px;          // padded extent = core extent + 2 halo
+    int halo;
+    int sgy, sgx;            // sub-grid chunks along y, x
+    int first, count;        // batch = sub-grid chunks [first, first + count)
+    int out_z0;              // output plane 0 is input plane out_z0
+};
+hipError_t launch_chunk_gather(const uint16_t* in, const ChunkBatch& cb, float offset, float* out,
+                               hipStream_t s);
+hipError_t launch_chunk_scatter(const float* est, const ChunkBatch& cb, float offset, uint16_t* out,
+                                hipStream_t s);
+
 // ---- chunk entropy coder (rans_kernels.hip) ----------------------------------------
 struct CodecGeom {
     int ts;                  // element bytes: 2 (uint16) or 4 (int32, zigzag mapped)

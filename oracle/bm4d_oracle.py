@@ -197,3 +197,36 @@ def decode_keys(keys16):
         s = np.array([int(k) & 0xFFFFF800], dtype=np.uint32).view(np.float32)[0]
         out.append((d, float(s) / 512.0))
     return out
+
+
+def padded_chunks(vol, chunk, halo, core=None):
+    """Chunk-local mode: yields ``(slices of the core, padded
+    array)`` for every chunk of the core planes ``core = (zc0, zc1)`` of ``vol`` -- cores of
+    ``chunk`` voxels (ragged last ones), read with ``halo`` voxels per side, indices clamped to the
+    array (edge replication)."""
+    vol = np.asarray(vol)
+    zc0, zc1 = (0, vol.shape[0]) if core is None else core
+    lo = (zc0, 0, 0)
+    hi = (zc1, vol.shape[1], vol.shape[2])
+    for z0 in range(lo[0], hi[0], chunk):
+        for y0 in range(lo[1], hi[1], chunk):
+            for x0 in range(lo[2], hi[2], chunk):
+                o = (z0, y0, x0)
+                e = [min(chunk, h - s) for s, h in zip(o, hi)]
+                idx = [np.clip(np.arange(s - halo, s + n + halo), 0, dim - 1)
+                       for s, n, dim in zip(o, e, vol.shape)]
+                padded = vol[np.ix_(*idx)]
+                yield tuple(slice(s, s + n) for s, n in zip(o, e)), np.ascontiguousarray(padded)
+
+
+def bm4d_u16_chunked(vol, sigma, offset, chunk, halo, stages=2, core=None, **kw):
+    """The identical padded arrays the chunk-local device call processes, one oracle pipeline
+    each; only the cores are written.  Returns the core planes."""
+    vol = np.ascontiguousarray(vol, dtype=np.uint16)
+    zc0, zc1 = (0, vol.shape[0]) if core is None else core
+    out = np.zeros((zc1 - zc0,) + vol.shape[1:], dtype=np.uint16)
+    for sl, padded in padded_chunks(vol, chunk, halo, core):
+        den = bm4d_u16(padded, sigma, offset, stages=stages, **kw)
+        inner = tuple(slice(halo, halo + (s.stop - s.start)) for s in sl)
+        out[(slice(sl[0].start - zc0, sl[0].stop - zc0),) + sl[1:]] = den[inner]
+    return out

@@ -17,6 +17,7 @@ from aind_exaspim_image_compression.distributed import plan_slabs
 
 SIGMA = 24.0
 SHAPE = (112, 24, 28)
+CHUNK_SHAPE = (48, 16, 12)
 
 
 def test_plan_slabs():
@@ -71,6 +72,63 @@ def _worker(rank, world, port, tmp):
     np.save(os.path.join(tmp, f"plan{rank}.npy"), np.array([plan.z0, plan.z1]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _chunk_worker(rank, world, port, tmp):
+    """Chunk-local mode (config 4) across ranks: raw uint16 planes exchanged, chunk layers that do
+    not need them denoised meanwhile; the oracle is the per-chunk compute."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "aind-exaspim-image-compression_amd"),
+              os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("OMP_NUM_THREADS", "2")
+    from aind_exaspim_image_compression.distributed import denoise_chunked_slab, plan_chunk_slabs
+    from oracle import bm4d_oracle as O
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    vol, _ = synth_volume(CHUNK_SHAPE, seed=22, as_u16=True)
+    plan = plan_chunk_slabs(CHUNK_SHAPE[0], world, rank, chunk=8, halo=4)
+    raw = torch.zeros((plan.p1 - plan.p0,) + CHUNK_SHAPE[1:], dtype=torch.int16)
+    raw[plan.core] = torch.from_numpy(vol[plan.z0:plan.z1].view(np.int16))   # own planes only
+    calls = []
+
+    def run_chunks(t, core):
+        calls.append(core)
+        out = O.bm4d_u16_chunked(t.numpy().view(np.uint16), SIGMA, 37.0, 8, 4, core=core)
+        return torch.from_numpy(out.view(np.int16))
+
+    out = denoise_chunked_slab(raw, plan, run_chunks, chunk=8)
+    np.save(os.path.join(tmp, f"cslab{rank}.npy"), out.numpy().view(np.uint16))
+    np.save(os.path.join(tmp, f"cplan{rank}.npy"), np.array([plan.z0, plan.z1, len(calls)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_chunk_local_equals_single_process(oracle, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_chunk_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    vol, _ = synth_volume(CHUNK_SHAPE, seed=22, as_u16=True)
+    want = oracle.bm4d_u16_chunked(vol, SIGMA, 37.0, 8, 4)
+    got = np.empty_like(want)
+    for r in range(world):
+        z0, z1, ncalls = np.load(tmp_path / f"cplan{r}.npy")
+        got[z0:z1] = np.load(tmp_path / f"cslab{r}.npy")
+        assert ncalls == 2            # interior layers first, then the layer next to the neighbour
+    # identical padded arrays through the identical code: bit-identical
+    np.testing.assert_array_equal(got, want)
+
+
+def test_plan_chunk_slabs():
+    from aind_exaspim_image_compression.distributed import plan_chunk_slabs
+    plans = [plan_chunk_slabs(2048, 8, r) for r in range(8)]       # BASELINE.json config 4
+    assert [p.z1 - p.z0 for p in plans] == [256] * 8
+    assert plans[0].p0 == 0 and plans[0].p1 == 264 and plans[3].p0 == 760 and plans[7].p1 == 2048
+    odd = [plan_chunk_slabs(1280, 2, r, chunk=256) for r in range(2)]
+    assert (odd[0].z1, odd[1].z0) == (512, 512)                    # whole chunk layers per rank
+    with pytest.raises(ValueError):
+        plan_chunk_slabs(256, 2, 0)
 
 
 def test_two_rank_slabs_equal_whole_volume(oracle, tmp_path):
