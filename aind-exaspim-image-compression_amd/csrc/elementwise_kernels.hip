@@ -328,8 +328,8 @@ hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz
 
 // ---- chunk-local mode (BASELINE config 4) ------------------------------
 // A batch of padded chunks: chunk (bz, by, bx) of a sub-grid has its core at (z0 + bz*cz, ...),
-// extent (ez, ey, ex), and is read with `halo` voxels on every side; indices beyond the buffer are
-// clamped (edge replication).  gather: u16 -> (float) - offset into [batch][pz][py][px];
+// extent (ez, ey, ex), and is read with (lz, ly, lx) voxels in front and (pz - ez - lz, ...) behind
+// it -- the halo, cut off where the buffer ends.  gather: u16 -> (float) - offset into [batch][pz][py][px];
 // scatter: the denoised padded chunks' cores -> + offset -> clip -> rint -> u16 into the output.
 __global__ __launch_bounds__(EW_THREADS) void chunk_gather_kernel(const uint16_t* __restrict__ in,
                                                                   ChunkBatch cb, float offset,
@@ -343,9 +343,9 @@ __global__ __launch_bounds__(EW_THREADS) void chunk_gather_kernel(const uint16_t
         const int x = (int)(r % cb.px), y = (int)((r / cb.px) % cb.py), z = (int)(r / ((size_t)cb.px * cb.py));
         const int c = cb.first + b;
         const int bx = c % cb.sgx, by = (c / cb.sgx) % cb.sgy, bz = c / (cb.sgx * cb.sgy);
-        const int gz = min(max(cb.z0 + bz * cb.cz - cb.halo + z, 0), cb.nz - 1);
-        const int gy = min(max(cb.y0 + by * cb.cy - cb.halo + y, 0), cb.ny - 1);
-        const int gx = min(max(cb.x0 + bx * cb.cx - cb.halo + x, 0), cb.nx - 1);
+        const int gz = min(max(cb.z0 + bz * cb.cz - cb.lz + z, 0), cb.nz - 1);
+        const int gy = min(max(cb.y0 + by * cb.cy - cb.ly + y, 0), cb.ny - 1);
+        const int gx = min(max(cb.x0 + bx * cb.cx - cb.lx + x, 0), cb.nx - 1);
         out[i] = (float)in[((size_t)gz * cb.ny + gy) * cb.nx + gx] - offset;
     }
 }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(EW_THREADS) void chunk_scatter_kernel(const float* 
         const int x = (int)(r % cb.ex), y = (int)((r / cb.ex) % cb.ey), z = (int)(r / ((size_t)cb.ex * cb.ey));
         const int c = cb.first + b;
         const int bx = c % cb.sgx, by = (c / cb.sgx) % cb.sgy, bz = c / (cb.sgx * cb.sgy);
-        const float v = est[(size_t)b * pvox + ((size_t)(z + cb.halo) * cb.py + (y + cb.halo)) * cb.px + (x + cb.halo)];
+        const float v = est[(size_t)b * pvox + ((size_t)(z + cb.lz) * cb.py + (y + cb.ly)) * cb.px + (x + cb.lx)];
         const int oz = cb.z0 + bz * cb.cz + z - cb.out_z0, oy = cb.y0 + by * cb.cy + y, ox = cb.x0 + bx * cb.cx + x;
         out[((size_t)oz * cb.ny + oy) * cb.nx + ox] = quantise_u16(v + offset, 65535.0f);
     }

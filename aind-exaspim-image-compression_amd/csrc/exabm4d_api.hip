@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/exabm4d.h"
 #include "exabm4d_kernels.h"
@@ -603,8 +604,29 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
                         scratch, 1);
 }
 
-// Chunk-local mode: every chunk (core + halo, edge-replicated at the buffer's faces) is denoised in
-// isolation, batches of equally shaped chunks per pipeline run; only the cores are written.
+// Chunk-local mode: every chunk (core + halo, the halo cut off where the buffer ends) is denoised
+// in isolation, batches of equally shaped chunks per pipeline run; only the cores are written.
+namespace {
+struct ChunkRun {
+    int i0, count;       // chunks [i0, i0 + count) of the axis ...
+    int e, lo, hi;       // ... share the core extent and the halo in front / behind
+};
+// chunks of `chunk` voxels tile [c0, c1) inside a buffer axis of n voxels
+std::vector<ChunkRun> chunk_runs(int n, int c0, int c1, int chunk, int halo) {
+    std::vector<ChunkRun> runs;
+    int i = 0;
+    for (int start = c0; start < c1; start += chunk, i++) {
+        const int e = std::min(chunk, c1 - start);
+        const int lo = std::min(halo, start), hi = std::min(halo, n - (start + e));
+        if (!runs.empty() && runs.back().e == e && runs.back().lo == lo && runs.back().hi == hi)
+            runs.back().count++;
+        else
+            runs.push_back({i, 1, e, lo, hi});
+    }
+    return runs;
+}
+}  // namespace
+
 int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
                                     int nx, int zc0, int zc1, int chunk, int halo, float sigma,
                                     float offset, const exabm4d_params* p, int stages) {
@@ -619,63 +641,52 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     rc = ensure_window(ctx, (double)p->kaiser_beta);
     if (rc) return rc;
-    const int ext[3] = {zc1 - zc0, ny, nx};
-    // per axis: `full[a]` chunks of `chunk` voxels, then one of rem[a] voxels when rem[a] > 0
-    int full[3], rem[3];
-    for (int a = 0; a < 3; a++) {
-        full[a] = ext[a] / chunk;
-        rem[a] = ext[a] - full[a] * chunk;
-        const int smallest = rem[a] ? rem[a] : chunk;
-        if (smallest + 2 * halo < 8)
-            return fail(ctx, EXABM4D_ERR_INVALID, "chunked: a padded chunk would be thinner than one block (8)");
-    }
+    const std::vector<ChunkRun> runs[3] = {chunk_runs(nz, zc0, zc1, chunk, halo),
+                                           chunk_runs(ny, 0, ny, chunk, halo),
+                                           chunk_runs(nx, 0, nx, chunk, halo)};
+    for (int a = 0; a < 3; a++)
+        for (const ChunkRun& r : runs[a])
+            if (r.e + r.lo + r.hi < 8)
+                return fail(ctx, EXABM4D_ERR_INVALID, "chunked: a padded chunk would be thinner than one block (8)");
     ctx->ev_used[EXABM4D_PHASE_COUNTS_FROM_U16] = false;
-    for (int cls = 0; cls < 8; cls++) {
-        // class bit a set: the ragged last chunk along axis a
-        int sg[3], e[3], o[3];
-        bool empty = false;
-        for (int a = 0; a < 3; a++) {
-            const bool ragged = (cls >> a) & 1;
-            sg[a] = ragged ? (rem[a] ? 1 : 0) : full[a];
-            e[a] = ragged ? rem[a] : chunk;
-            o[a] = ragged ? full[a] * chunk : 0;
-            if (sg[a] == 0) empty = true;
-        }
-        if (empty) continue;
-        ChunkBatch cb;
-        cb.nz = nz; cb.ny = ny; cb.nx = nx;
-        cb.z0 = zc0 + o[0]; cb.y0 = o[1]; cb.x0 = o[2];
-        cb.cz = cb.cy = cb.cx = chunk;
-        cb.ez = e[0]; cb.ey = e[1]; cb.ex = e[2];
-        cb.halo = halo;
-        cb.pz = e[0] + 2 * halo; cb.py = e[1] + 2 * halo; cb.px = e[2] + 2 * halo;
-        cb.sgy = sg[1]; cb.sgx = sg[2];
-        cb.out_z0 = zc0;
-        const long long nchunks = (long long)sg[0] * sg[1] * sg[2];
-        const size_t per = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, 1, stages) +
-                           align256((size_t)cb.pz * cb.py * cb.px * sizeof(float));
-        long long bmax = (long long)(((size_t)ctx->chunk_budget_mb << 20) / per);
-        if (bmax < 1) bmax = 1;
-        if (bmax > 65535) bmax = 65535;
-        for (long long first = 0; first < nchunks; first += bmax) {
-            const int count = (int)std::min<long long>(bmax, nchunks - first);
-            cb.first = (int)first;
-            cb.count = count;
-            VolGeom g;
-            rc = make_geom(ctx, cb.pz, cb.py, cb.px, count, g);
-            if (rc) return rc;
-            const size_t n = (size_t)g.nvox * (size_t)count;
-            const size_t base = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, count, stages);
-            rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
-            if (rc) return rc;
-            char* scratch = static_cast<char*>(ctx->scratch);
-            float* vol = reinterpret_cast<float*>(scratch + base);
-            HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream));
-            rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f, scratch, 1);
-            if (rc) return rc;
-            HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
-        }
-    }
+    for (const ChunkRun& rz : runs[0])
+        for (const ChunkRun& ry : runs[1])
+            for (const ChunkRun& rx : runs[2]) {
+                ChunkBatch cb;
+                cb.nz = nz; cb.ny = ny; cb.nx = nx;
+                cb.z0 = zc0 + rz.i0 * chunk; cb.y0 = ry.i0 * chunk; cb.x0 = rx.i0 * chunk;
+                cb.cz = cb.cy = cb.cx = chunk;
+                cb.ez = rz.e; cb.ey = ry.e; cb.ex = rx.e;
+                cb.lz = rz.lo; cb.ly = ry.lo; cb.lx = rx.lo;
+                cb.pz = rz.e + rz.lo + rz.hi; cb.py = ry.e + ry.lo + ry.hi; cb.px = rx.e + rx.lo + rx.hi;
+                cb.sgy = ry.count; cb.sgx = rx.count;
+                cb.out_z0 = zc0;
+                const long long nchunks = (long long)rz.count * ry.count * rx.count;
+                const size_t per = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, 1, stages) +
+                                   align256((size_t)cb.pz * cb.py * cb.px * sizeof(float));
+                long long bmax = (long long)(((size_t)ctx->chunk_budget_mb << 20) / per);
+                if (bmax < 1) bmax = 1;
+                if (bmax > 65535) bmax = 65535;
+                for (long long first = 0; first < nchunks; first += bmax) {
+                    const int count = (int)std::min<long long>(bmax, nchunks - first);
+                    cb.first = (int)first;
+                    cb.count = count;
+                    VolGeom g;
+                    rc = make_geom(ctx, cb.pz, cb.py, cb.px, count, g);
+                    if (rc) return rc;
+                    const size_t n = (size_t)g.nvox * (size_t)count;
+                    const size_t base = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, count, stages);
+                    rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+                    if (rc) return rc;
+                    char* scratch = static_cast<char*>(ctx->scratch);
+                    float* vol = reinterpret_cast<float*>(scratch + base);
+                    HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream));
+                    rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f,
+                                      scratch, 1);
+                    if (rc) return rc;
+                    HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
+                }
+            }
     return EXABM4D_OK;
 }
 

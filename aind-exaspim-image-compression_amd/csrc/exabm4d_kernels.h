@@ -75,8 +75,8 @@ struct ChunkBatch {
     int z0, y0, x0;          // core origin of sub-grid chunk (0, 0, 0)
     int cz, cy, cx;          // core pitch of the chunk grid
     int ez, ey, ex;          // core extent of the chunks of this sub-grid (<= pitch)
-    int pz, py, px;          // padded extent = core extent + 2 halo
-    int halo;
+    int pz, py, px;          // padded extent = halo in front (cut at the buffer) + core + halo behind
+    int lz, ly, lx;          // voxels in front of the core inside the padded chunk
     int sgy, sgx;            // sub-grid chunks along y, x
     int first, count;        // batch = sub-grid chunks [first, first + count)
     int out_z0;              // output plane 0 is input plane out_z0

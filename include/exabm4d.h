@@ -195,9 +195,9 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
  * like the reference's one-bm4d()-call-per-patch pool (scripts/precompute.py:215-228).  The core
  * planes [zc0, zc1) of the input buffer `in` [nz][ny][nx] are tiled by cubic chunks of `chunk`
  * voxels (ragged last chunks allowed), chunk grid origin (zc0, 0, 0).  Every chunk is read with
- * `halo` voxels on each side -- indices beyond the buffer are clamped (edge replication at the
- * volume's faces; planes of `in` outside [zc0, zc1) are real neighbour data, e.g. a slab's
- * exchanged halo) -- and denoised IN ISOLATION by the uint16 pipeline of exabm4d_denoise_u16_dev
+ * `halo` voxels on each side -- the read window is clamped to the buffer: no padding is invented
+ * at the volume's faces; planes of `in` outside [zc0, zc1) are real neighbour data, e.g. a slab's
+ * exchanged halo -- and denoised IN ISOLATION by the uint16 pipeline of exabm4d_denoise_u16_dev
  * (reference grid and search clamped to the padded chunk); only its core is written, to
  * out[(zc1 - zc0)][ny][nx].  Chunks of one shape are batched per pipeline run (scratch per batch
  * bounded by option "chunk_budget_mb", default 32768).  The oracle processes the identical padded

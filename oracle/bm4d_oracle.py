@@ -200,10 +200,10 @@ def decode_keys(keys16):
 
 
 def padded_chunks(vol, chunk, halo, core=None):
-    """Chunk-local mode: yields ``(slices of the core, padded
-    array)`` for every chunk of the core planes ``core = (zc0, zc1)`` of ``vol`` -- cores of
-    ``chunk`` voxels (ragged last ones), read with ``halo`` voxels per side, indices clamped to the
-    array (edge replication)."""
+    """Chunk-local mode: yields ``(slices of the core, halo in
+    front per axis, padded array)`` for every chunk of the core planes ``core = (zc0, zc1)`` of
+    ``vol`` -- cores of ``chunk`` voxels (ragged last ones), read with ``halo`` voxels per side,
+    the read window clamped to the array (no padding is invented at the faces)."""
     vol = np.asarray(vol)
     zc0, zc1 = (0, vol.shape[0]) if core is None else core
     lo = (zc0, 0, 0)
@@ -213,10 +213,11 @@ def padded_chunks(vol, chunk, halo, core=None):
             for x0 in range(lo[2], hi[2], chunk):
                 o = (z0, y0, x0)
                 e = [min(chunk, h - s) for s, h in zip(o, hi)]
-                idx = [np.clip(np.arange(s - halo, s + n + halo), 0, dim - 1)
-                       for s, n, dim in zip(o, e, vol.shape)]
-                padded = vol[np.ix_(*idx)]
-                yield tuple(slice(s, s + n) for s, n in zip(o, e)), np.ascontiguousarray(padded)
+                front = [min(halo, s) for s in o]
+                win = tuple(slice(s - f, min(dim, s + n + halo))
+                            for s, n, f, dim in zip(o, e, front, vol.shape))
+                yield (tuple(slice(s, s + n) for s, n in zip(o, e)), front,
+                       np.ascontiguousarray(vol[win]))
 
 
 def bm4d_u16_chunked(vol, sigma, offset, chunk, halo, stages=2, core=None, **kw):
@@ -225,8 +226,8 @@ def bm4d_u16_chunked(vol, sigma, offset, chunk, halo, stages=2, core=None, **kw)
     vol = np.ascontiguousarray(vol, dtype=np.uint16)
     zc0, zc1 = (0, vol.shape[0]) if core is None else core
     out = np.zeros((zc1 - zc0,) + vol.shape[1:], dtype=np.uint16)
-    for sl, padded in padded_chunks(vol, chunk, halo, core):
+    for sl, front, padded in padded_chunks(vol, chunk, halo, core):
         den = bm4d_u16(padded, sigma, offset, stages=stages, **kw)
-        inner = tuple(slice(halo, halo + (s.stop - s.start)) for s in sl)
+        inner = tuple(slice(f, f + (s.stop - s.start)) for f, s in zip(front, sl))
         out[(slice(sl[0].start - zc0, sl[0].stop - zc0),) + sl[1:]] = den[inner]
     return out
