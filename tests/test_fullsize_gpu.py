@@ -72,10 +72,9 @@ def test_two_stage_parity_on_a_multi_tile_volume(ctx, oracle):
     assert abs(psnr(got, clean + 37, peak) - psnr(want, clean + 37, peak)) < 1e-3
 
 
-def test_full_size_1024_properties(ctx):
-    """1024^3 uint16 (BASELINE.json configs[2]): (a) locality / crop invariance -- the interior of
-    a separately denoised 256^3 crop whose origin is a multiple of 4 equals the same voxels of
-    the full result (dependency radius 48); (b) the removed residual has the noise's variance."""
+@pytest.fixture(scope="module")
+def full1024(ctx):
+    """(noisy, denoised) 1024^3 uint16 volumes of BASELINE.json configs[2] / [4], host arrays."""
     import bench
     n = 1024
     vol = bench.synth_u16((n, n, n), seed=5)
@@ -86,6 +85,15 @@ def test_full_size_1024_properties(ctx):
     full = d_out.download((n, n, n), np.uint16)
     d_in.free()
     d_out.free()
+    return vol, full
+
+
+def test_full_size_1024_properties(full1024):
+    """1024^3 uint16 (BASELINE.json configs[2]): (a) locality / crop invariance -- the interior of
+    a separately denoised 256^3 crop whose origin is a multiple of 4 equals the same voxels of
+    the full result (dependency radius 48); (b) the removed residual has the noise's variance."""
+    import bench
+    vol, full = full1024
     o = (384, 512, 300)
     crop = np.ascontiguousarray(vol[o[0]:o[0] + 256, o[1]:o[1] + 256, o[2]:o[2] + 256])
     from aind_exaspim_image_compression.bm4d import denoise_volume
@@ -96,3 +104,113 @@ def test_full_size_1024_properties(ctx):
     resid = full[::8, ::8, ::8].astype(np.float32) - vol[::8, ::8, ::8].astype(np.float32)
     assert 0.8 * SIGMA < resid.std() < 1.05 * SIGMA
     assert abs(resid.mean()) < 0.5
+
+
+def _oracle_crop_check(oracle, vol, got, origin, edge, radius, stages):
+    """The oracle on a crop whose origin is a multiple of 4 reproduces the full-size result on the
+    crop's interior (everything further than the dependency radius from the crop's faces)."""
+    o, e, r = origin, edge, radius
+    assert all(v % 4 == 0 for v in o)
+    crop = np.ascontiguousarray(vol[o[0]:o[0] + e, o[1]:o[1] + e, o[2]:o[2] + e])
+    want = oracle.bm4d_u16(crop, SIGMA, 37.0, stages=stages)[r:e - r, r:e - r, r:e - r]
+    have = got[o[0] + r:o[0] + e - r, o[1] + r:o[1] + e - r, o[2] + r:o[2] + e - r]
+    d = np.abs(have.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (origin, int(d.max()), float(np.mean(d > 0)))
+    ref = crop[r:e - r, r:e - r, r:e - r].astype(np.float64)       # PSNR against the noisy input:
+    peak = 65535.0                                                   # same reference for both
+    assert abs(psnr(have, ref, peak) - psnr(want, ref, peak)) < 0.01
+
+
+def test_config3_1024_against_the_oracle_on_interior_crops(full1024, oracle):
+    """BASELINE.json configs[2] (1024^3, two stages) anchored on the ORACLE: two 144^3 crops at
+    different depths, interiors of 48^3 voxels (dependency radius 48 for two stages): uint16
+    within one count, PSNR difference < 0.01 dB."""
+    vol, full = full1024
+    for origin in ((400, 516, 128), (40, 860, 700)):
+        _oracle_crop_check(oracle, vol, full, origin, 144, 48, 2)
+
+
+def test_config2_256_against_the_oracle_on_interior_crops(ctx, oracle):
+    """BASELINE.json configs[1] (256^3, hard-threshold stage + aggregation) against the oracle on
+    two interior crops (radius 24 for one stage), and the two-stage result of the same volume on
+    one crop."""
+    import bench
+    vol = bench.synth_u16((256, 256, 256), seed=9)
+    d_in = ctx.to_device(vol)
+    d_out = ctx.alloc(vol.nbytes)
+    try:
+        ctx.denoise_u16(d_in, d_out, vol.shape, SIGMA, 37.0, stages=1)
+        ctx.sync()
+        ht = d_out.download(vol.shape, np.uint16)
+        ctx.denoise_u16(d_in, d_out, vol.shape, SIGMA, 37.0, stages=2)
+        ctx.sync()
+        two = d_out.download(vol.shape, np.uint16)
+    finally:
+        d_in.free()
+        d_out.free()
+    for origin in ((0, 0, 0), (112, 60, 144)):              # one crop shares three volume faces
+        _oracle_crop_check(oracle, vol, ht, origin, 112, 24, 1)
+    _oracle_crop_check(oracle, vol, two, (64, 128, 20), 128, 48, 2)
+
+
+def test_config5_chain_at_1024(full1024, ctx):
+    """BASELINE.json configs[4] at full size: denoised volume -> (a) lossless chunk coder, decode
+    == input; (b) 8^3 block DCT quantiser -> chunk coder on the indices -> decode == indices ->
+    dequantise: error bounded by the step.  Three chunk streams are compared with the oracle's
+    bytes; the coded sizes sit between the order-0 entropy floor and 1.01 x floor."""
+    from aind_exaspim_image_compression import _native
+    from oracle import codec_oracle as co
+    vol, full = full1024
+    n = 1024
+    shape = (n, n, n)
+    dev = torch.device("cuda", 0)
+    t_full = torch.from_numpy(full.view(np.int16)).to(dev)
+    ctx.sync()
+
+    def encode(t_src, ts, vshape, chunk):
+        nchunks = int(np.prod([-(-a // c) for a, c in zip(vshape, chunk)]))
+        cap = _native.codec_volume_bound(ts, vshape, chunk)
+        t_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        t_off = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+        t_sz = torch.empty(nchunks, dtype=torch.int32, device=dev)
+        exact, container = ctx.codec_encode(t_src, ts, vshape, chunk, out=t_out, out_capacity=cap,
+                                            offsets=t_off, sizes=t_sz)
+        assert container <= cap and int(t_sz.sum()) == exact
+        return t_out, t_off, t_sz, exact
+
+    # (a) lossless leg on the denoised uint16 volume, 64^3 chunks
+    t_out, t_off, t_sz, exact = encode(t_full, 2, shape, (64, 64, 64))
+    t_back = torch.empty_like(t_full)
+    ctx.codec_decode(t_out, t_off, 2, shape, (64, 64, 64), t_back)
+    assert torch.equal(t_back, t_full)
+    off, sz = t_off.cpu().numpy(), t_sz.cpu().numpy()
+    for c in (0, 1234, 4095):
+        cz, cy, cx = c // 256, (c // 16) % 16, c % 16
+        chunk = full[64 * cz:64 * cz + 64, 64 * cy:64 * cy + 64, 64 * cx:64 * cx + 64]
+        want = co.encode(chunk)
+        got = t_out[int(off[c]):int(off[c]) + int(sz[c])].cpu().numpy().tobytes()
+        assert got == want, f"chunk {c}"
+        floor = co.plane_entropy_bytes(chunk)
+        assert floor <= len(want) <= 1.01 * floor + 16 + 2 * (32 + 512 + 256)
+    assert 2.5 < 2.0 * n ** 3 / exact < 20.0                 # denoised data compress; raw ~2
+    del t_out, t_back
+    # (b) config 5's lossy leg
+    q = 8.0
+    nblk = (n // 8) ** 3
+    t_idx = torch.empty(nblk * 512, dtype=torch.int32, device=dev)
+    ctx.dctq_forward(t_full, shape, q, t_idx)
+    ishape, ichunk = (nblk, 8, 64), (512, 8, 64)
+    t_out, t_off, t_sz, exact_i = encode(t_idx, 4, ishape, ichunk)
+    t_iback = torch.empty_like(t_idx)
+    ctx.codec_decode(t_out, t_off, 4, ishape, ichunk, t_iback)
+    assert torch.equal(t_iback, t_idx)
+    first = t_idx[:1 << 18].cpu().numpy()
+    o0, s0 = int(t_off[0]), int(t_sz[0])
+    assert t_out[o0:o0 + s0].cpu().numpy().tobytes() == co.encode(first)
+    t_rec = torch.empty_like(t_full)
+    ctx.dctq_inverse(t_iback, shape, q, t_rec)
+    ctx.sync()
+    err = (t_rec.to(torch.int32) & 0xFFFF) - (t_full.to(torch.int32) & 0xFFFF)
+    assert int(err.abs().max()) <= 0.5 * q * np.sqrt(512.0) + 1.0
+    assert float(err.float().abs().mean()) < 0.5 * q
+    assert exact_i < exact                                    # the lossy leg is the smaller one
