@@ -131,15 +131,26 @@ static int ensure_window(exabm4d_ctx* ctx, double beta) {
     ctx->win_beta = beta;
     return EXABM4D_OK;
 }
+// Block matching's `guarded` variant streams whole plane rows by LDS-DMA and reads up to 124 bytes
+// in front of the first and past the last row of the volume (bm_tile_kernel): such a volume must
+// lie inside the scratch allocation with 256 mapped bytes on either side.
+constexpr size_t GUARD_BYTES = 256;
+static bool guarded_region_ok(const exabm4d_ctx* ctx, const void* ptr, size_t bytes) {
+    const char* lo = static_cast<const char*>(ctx->scratch);
+    const char* hi = lo + ctx->scratch_bytes + GUARD_BYTES;      // ensure_scratch allocates + GUARD_BYTES
+    const char* p = static_cast<const char*>(ptr);
+    return ctx->scratch && p >= lo + GUARD_BYTES && p + bytes + GUARD_BYTES <= hi;
+}
 static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return EXABM4D_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
-    // + 256: block matching reads up to 124 bytes past the last row of the library's own volumes
-    // (bm_tile_kernel, `guarded`); the region in front of each of them is another scratch region
-    hipError_t e = hipMalloc(&ctx->scratch, bytes + 256);
+    // + GUARD_BYTES: block matching reads up to 124 bytes past the last row of the library's own
+    // volumes (bm_tile_kernel, `guarded`); the region in front of each of them is another scratch
+    // region (checked per launch: guarded_region_ok)
+    hipError_t e = hipMalloc(&ctx->scratch, bytes + GUARD_BYTES);
     if (e != hipSuccess) {
         char msg[160];
         std::snprintf(msg, sizeof msg, "device scratch allocation of %zu bytes failed: %s", bytes,
@@ -150,6 +161,7 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     return EXABM4D_OK;
 }
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
 
 static int make_tfdev(exabm4d_ctx* ctx, const exabm4d_transform* t, TfDev& d) {
     if (!t) return fail(ctx, EXABM4D_ERR_INVALID, "transform is NULL");
@@ -175,6 +187,27 @@ static int make_tfdev(exabm4d_ctx* ctx, const exabm4d_transform* t, TfDev& d) {
     d.range = (float)(t->mx - t->mn);
     return EXABM4D_OK;
 }
+
+namespace {
+struct ChunkRun {
+    int i0, count;       // chunks [i0, i0 + count) of the axis ...
+    int e, lo, hi;       // ... share the core extent and the halo in front / behind
+};
+// chunks of `chunk` voxels tile [c0, c1) inside a buffer axis of n voxels
+std::vector<ChunkRun> chunk_runs(int n, int c0, int c1, int chunk, int halo) {
+    std::vector<ChunkRun> runs;
+    int i = 0;
+    for (int start = c0; start < c1; start += chunk, i++) {
+        const int e = std::min(chunk, c1 - start);
+        const int lo = std::min(halo, start), hi = std::min(halo, n - (start + e));
+        if (!runs.empty() && runs.back().e == e && runs.back().lo == lo && runs.back().hi == hi)
+            runs.back().count++;
+        else
+            runs.push_back({i, 1, e, lo, hi});
+    }
+    return runs;
+}
+}  // namespace
 
 extern "C" {
 
@@ -400,6 +433,8 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
         rc = ensure_scratch(ctx, bytes + 512);
         if (rc) return rc;
         char* base = static_cast<char*>(ctx->scratch);
+        if (!guarded_region_ok(ctx, base + 256, bytes))
+            return fail(ctx, EXABM4D_ERR_INVALID, "internal: guarded volume without mapped slack around it");
         HIP_TRY(ctx, hipMemsetAsync(base, 0xFF, bytes + 512, ctx->stream));      // NaN bit patterns
         HIP_TRY(ctx, hipMemcpyAsync(base + 256, vol, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, launch_blockmatch(reinterpret_cast<const float*>(base + 256), g, batch,
@@ -507,6 +542,9 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     hipStream_t s = ctx->stream;
     if (ctx->profile)
         for (int i = 1; i < EXABM4D_PHASE_COUNT; i++) ctx->ev_used[i] = false;
+    if ((noisy_guarded && !guarded_region_ok(ctx, noisy, n * sizeof(float))) ||
+        (stages >= 2 && !guarded_region_ok(ctx, basic, n * sizeof(float))))
+        return fail(ctx, EXABM4D_ERR_INVALID, "internal: guarded volume without mapped slack around it");
 
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_1);
@@ -606,26 +644,6 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
 
 // Chunk-local mode: every chunk (core + halo, the halo cut off where the buffer ends) is denoised
 // in isolation, batches of equally shaped chunks per pipeline run; only the cores are written.
-namespace {
-struct ChunkRun {
-    int i0, count;       // chunks [i0, i0 + count) of the axis ...
-    int e, lo, hi;       // ... share the core extent and the halo in front / behind
-};
-// chunks of `chunk` voxels tile [c0, c1) inside a buffer axis of n voxels
-std::vector<ChunkRun> chunk_runs(int n, int c0, int c1, int chunk, int halo) {
-    std::vector<ChunkRun> runs;
-    int i = 0;
-    for (int start = c0; start < c1; start += chunk, i++) {
-        const int e = std::min(chunk, c1 - start);
-        const int lo = std::min(halo, start), hi = std::min(halo, n - (start + e));
-        if (!runs.empty() && runs.back().e == e && runs.back().lo == lo && runs.back().hi == hi)
-            runs.back().count++;
-        else
-            runs.push_back({i, 1, e, lo, hi});
-    }
-    return runs;
-}
-}  // namespace
 
 int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
                                     int nx, int zc0, int zc1, int chunk, int halo, float sigma,

@@ -114,6 +114,24 @@ def test_unet_on_rocm_matches_reference_cpu_output():
     np.testing.assert_allclose(y, ref, atol=2e-3, rtol=1e-3)      # fp32 MIOpen vs fp32 CPU
 
 
+def test_n2v2_on_rocm_and_shape_contract():
+    """N2V2UNet on ROCm against the reference's fp32 CPU output (fixture generated by importing
+    the reference), and the shape contract of reference unet3d.py:574-590 at sizes 64 and 65."""
+    torch.manual_seed(0)
+    model = unet3d.N2V2UNet().cuda().eval()
+    gold = np.load(os.path.join(GOLD, "n2v2.npz"))
+    for name, shape in (("cube32", (1, 1, 32, 32, 32)), ("odd", (1, 1, 33, 32, 35))):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            y = model(x.cuda()).cpu().numpy()
+        np.testing.assert_allclose(y, gold[name], atol=2e-3, rtol=1e-3)
+    for net in (model, unet3d.UNet().cuda().eval()):
+        for size in (64, 65):
+            x = torch.randn(1, 1, size, size, size, device="cuda")
+            with torch.no_grad():
+                assert net(x).shape == x.shape
+
+
 def test_predict_with_unet_and_predict_patch():
     torch.manual_seed(0)
     model = unet3d.UNet().cuda().eval()
