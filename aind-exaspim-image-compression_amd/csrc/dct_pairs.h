@@ -68,6 +68,68 @@ __device__ __forceinline__ void dct8_inv2(const DctTable& T, f2 (&v)[8]) {
     for (int n = 0; n < 8; n++) v[n] = x[n];
 }
 
+// ---- the same chains from the table's 7 distinct magnitudes -----------------------------------------
+// D[u][n] = s_u cos((2n + 1) u pi / 16) takes only seven absolute values (bit-identical after the one
+// rounding to fp32: checked by make_dct7): c = D[0][*] = |D[4][*]|, a, b = D[2][0], D[2][1],
+// e, f, g, h = D[1][0..3].  A kernel that receives the 64-entry table by value keeps it in 64
+// scalar registers and spills scalars by the dozen (v_writelane / v_readlane in the inner loops);
+// seven fit easily.  Signs move onto the vector operand -- fma(-c, v, t) and fma(c, -v, t) are the
+// same IEEE operation, and the negation is a free source modifier -- so every result is
+// bit-identical to the table form and to the oracle.
+struct Dct7 {
+    float c, a, b, e, f, g, h;
+};
+inline bool make_dct7(const DctTable& T, Dct7& q) {
+    q.c = T.d[0];
+    q.a = T.d[2 * 8 + 0];
+    q.b = T.d[2 * 8 + 1];
+    q.e = T.d[1 * 8 + 0];
+    q.f = T.d[1 * 8 + 1];
+    q.g = T.d[1 * 8 + 2];
+    q.h = T.d[1 * 8 + 3];
+    const float want[8][4] = {{q.c, q.c, q.c, q.c},     {q.e, q.f, q.g, q.h},   {q.a, q.b, -q.b, -q.a},
+                              {q.f, -q.h, -q.e, -q.g},  {q.c, -q.c, -q.c, q.c}, {q.g, -q.e, q.h, q.f},
+                              {q.b, -q.a, q.a, -q.b},   {q.h, -q.g, q.f, -q.e}};
+    for (int u = 0; u < 8; u++)
+        for (int n = 0; n < 4; n++)
+            if (T.d[u * 8 + n] != want[u][n]) return false;
+    return true;
+}
+__device__ __forceinline__ void dct8_fwd2(const Dct7& q, f2 (&v)[8]) {
+    f2 s[4], d[4], o[8];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s[n] = v[n] + v[7 - n];
+        d[n] = v[n] - v[7 - n];
+    }
+    o[0] = chain4p(q.c, s[0], q.c, s[1], q.c, s[2], q.c, s[3]);
+    o[2] = chain4p(q.a, s[0], q.b, s[1], q.b, -s[2], q.a, -s[3]);
+    o[4] = chain4p(q.c, s[0], q.c, -s[1], q.c, -s[2], q.c, s[3]);
+    o[6] = chain4p(q.b, s[0], q.a, -s[1], q.a, s[2], q.b, -s[3]);
+    o[1] = chain4p(q.e, d[0], q.f, d[1], q.g, d[2], q.h, d[3]);
+    o[3] = chain4p(q.f, d[0], q.h, -d[1], q.e, -d[2], q.g, -d[3]);
+    o[5] = chain4p(q.g, d[0], q.e, -d[1], q.h, d[2], q.f, d[3]);
+    o[7] = chain4p(q.h, d[0], q.g, -d[1], q.f, d[2], q.e, -d[3]);
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = o[u];
+}
+__device__ __forceinline__ void dct8_inv2(const Dct7& q, f2 (&v)[8]) {
+    f2 ev[4], od[4];
+    ev[0] = chain4p(q.c, v[0], q.a, v[2], q.c, v[4], q.b, v[6]);
+    ev[1] = chain4p(q.c, v[0], q.b, v[2], q.c, -v[4], q.a, -v[6]);
+    ev[2] = chain4p(q.c, v[0], q.b, -v[2], q.c, -v[4], q.a, v[6]);
+    ev[3] = chain4p(q.c, v[0], q.a, -v[2], q.c, v[4], q.b, -v[6]);
+    od[0] = chain4p(q.e, v[1], q.f, v[3], q.g, v[5], q.h, v[7]);
+    od[1] = chain4p(q.f, v[1], q.h, -v[3], q.e, -v[5], q.g, -v[7]);
+    od[2] = chain4p(q.g, v[1], q.e, -v[3], q.h, v[5], q.f, v[7]);
+    od[3] = chain4p(q.h, v[1], q.g, -v[3], q.f, v[5], q.e, -v[7]);
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        v[n] = ev[n] + od[n];
+        v[7 - n] = ev[n] - od[n];
+    }
+}
+
 // ---- the same 8-point transforms on the matrix pipe ------------------------------------------------
 // v_mfma_f32_4x4x1_16b_f32 does 16 independent 4x4 outer products: lane l = 4 b + r supplies
 // A_b[r] and B_b[r], register i of lane l accumulates D_b[i][r] += A_b[i] * B_b[r] with ONE fp32

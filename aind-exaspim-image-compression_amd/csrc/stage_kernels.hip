@@ -734,51 +734,46 @@ __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict_
     }
 }
 
-// Wiener counterparts.  Spectrum layout S[j][2 kl + c]: coefficient plane j of local block kl,
-// c = 0 noisy, c = 1 basic estimate, so the forward Haar transforms of both run as one packed
-// stream.  Local part: Haar over the half, Wiener-filter the detail coefficients (W = e / (e +
-// sigma^2) from the basic estimate, evaluated as e * rcp: see shrink_wiener), hand back the
-// (noisy, basic) approximation pairs.  The filtered details stay in the noisy slots.
+// Wiener counterparts.  The noisy and the basic-estimate groups keep separate spectra, both in the
+// hard-threshold layout (S[jp][2 kl + c] = coefficient plane 2 jp + c of local block kl), so that
+// (i) blocks (kl, kl + 1) of one volume are the two packed streams of a transform, exactly as in
+// the hard-threshold kernel, (ii) the basic spectrum is dead once the weights are known -- a wave
+// holds 128 spectrum registers only between the forward transforms and the local shrinkage, 64
+// afterwards -- and (iii) the inverse half is the hard-threshold code.  (The first version
+// interleaved noisy and basic in one 128-register array that stayed live to the end and spilled
+// 54 registers per lane: 280 GB of scratch traffic per 1024^3 launch.)
+// Local part: Haar over the half of both spectra, Wiener-filter the detail coefficients
+// (W = e / (e + sigma^2) from the basic estimate, evaluated as e * rcp: see shrink_wiener), hand
+// back the approximation pairs.  The filtered details stay in S.
 template <int KH>
-__device__ __forceinline__ void wiener_half_local(f16v (&S)[8], float sigma2, float& sw,
-                                                  f2 (&approx)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        f16v A = S[j];
-        f2 x[MAXG];
-#pragma unroll
-        for (int k = 0; k < KH; k++) x[k] = mk2(A[2 * k], A[2 * k + 1]);
-        haar_fwd2<KH>(x);
-        approx[j] = x[0];
-#pragma unroll
-        for (int k = 1; k < KH; k++) {
-            const float e = x[k].y * x[k].y;
-            const float W = e * __builtin_amdgcn_rcpf(e + sigma2);
-            sw += W * W;
-            A[2 * k] = W * x[k].x;
-        }
-        S[j] = A;
-    }
-}
-// Inverse Haar over the half of the filtered noisy coefficients, two planes per packed stream;
-// the estimates land in the noisy slots S[j][2 kl].
-template <int KH>
-__device__ __forceinline__ void wiener_half_unlocal(f16v (&S)[8], const float (&mine)[8]) {
+__device__ __forceinline__ void wiener_half_local(f16v (&S)[4], const f16v (&SB)[4], float sigma2,
+                                                  float& sw, f2 (&approx)[8]) {
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) {
-        f16v A = S[2 * jp], B = S[2 * jp + 1];
-        f2 x[MAXG];
-        x[0] = mk2(mine[2 * jp], mine[2 * jp + 1]);
-#pragma unroll
-        for (int k = 1; k < KH; k++) x[k] = mk2(A[2 * k], B[2 * k]);
-        haar_inv2<KH>(x);
+        f16v A = S[jp];
+        const f16v B = SB[jp];
+        f2 x[MAXG], y[MAXG];
 #pragma unroll
         for (int k = 0; k < KH; k++) {
-            A[2 * k] = x[k].x;
-            B[2 * k] = x[k].y;
+            x[k] = mk2(A[2 * k], A[2 * k + 1]);
+            y[k] = mk2(B[2 * k], B[2 * k + 1]);
         }
-        S[2 * jp] = A;
-        S[2 * jp + 1] = B;
+        haar_fwd2<KH>(x);
+        haar_fwd2<KH>(y);
+        approx[jp] = x[0];
+        approx[4 + jp] = y[0];
+#pragma unroll
+        for (int k = 1; k < KH; k++) {
+            const f2 e = y[k] * y[k];
+            const f2 t = e + sigma2;
+            const f2 W = e * mk2(__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y));
+            sw += W.x * W.x;
+            sw += W.y * W.y;
+            const f2 f = W * x[k];
+            A[2 * k] = f.x;
+            A[2 * k + 1] = f.y;
+        }
+        S[jp] = A;
     }
 }
 
@@ -789,7 +784,8 @@ template <bool WIENER, typename TableT>
 __device__ __forceinline__ bool process_half_group(
     const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
     int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
-    const float (&win)[8], float thr, float sigma2, ring_t* ring, float* __restrict__ cvol, f2* tb,
+    const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, ring_t* ring,
+    float* __restrict__ cvol, f2* tb,
     f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
@@ -809,9 +805,14 @@ __device__ __forceinline__ bool process_half_group(
 
     int closer = 0;
     if (active) {
-        f16v S[NP];
+        f16v S[4];                             // (noisy) spectrum of my blocks
+        f16v SB[WIENER ? 4 : 1];               // Wiener: basic-estimate spectrum, dead after the local step
 #pragma unroll
-        for (int j = 0; j < NP; j++) S[j] = (f16v)(0.0f);
+        for (int j = 0; j < 4; j++) S[j] = (f16v)(0.0f);
+        if constexpr (WIENER) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) SB[j] = (f16v)(0.0f);
+        }
 
         int my_dz, my_dy, my_dx;
         code_to_disp(mykey & KEY_CMASK, my_dz, my_dy, my_dx);
@@ -825,58 +826,75 @@ __device__ __forceinline__ bool process_half_group(
             const unsigned hi32 = __builtin_amdgcn_readlane(my_corner_hi, k);
             return ((size_t)hi32 << 32) | lo32;
         };
-        // Forward transforms of my blocks, two streams per iteration -- (noisy kl, basic kl) for
-        // Wiener, blocks (kl, kl + 1) for the hard threshold -- with the next gather in flight.
-        constexpr int kstep = WIENER ? 1 : 2;
-        float a[8], b[8], na[8] = {}, nb[8] = {};
+        // Forward transforms of my blocks, two streams per transform: blocks (kl, kl + 1) of one
+        // volume (a half of one block pairs the noisy block with the basic one in the Wiener
+        // stage, and runs the block twice in the hard-threshold stage).
+        float a[8], b[8];
         f2 v2[8];
-        {
-            const size_t c0 = corner_of(kb);
-            gather8(noisy + c0, sy, sz, hi, lo, a);
-            if constexpr (WIENER)
-                gather8(basic + c0, sy, sz, hi, lo, b);
-            else
-                gather8(noisy + corner_of(kb + (KH > 1 ? 1 : 0)), sy, sz, hi, lo, b);
-        }
-        for (int kl = 0; kl < KH; kl += kstep) {
-            if constexpr (!WIENER) {
-                if (kl + kstep < KH) {
+        if constexpr (!WIENER) {
+            float na[8] = {}, nb[8] = {};
+            gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
+            gather8(noisy + corner_of(kb + (KH > 1 ? 1 : 0)), sy, sz, hi, lo, b);
+            for (int kl = 0; kl < KH; kl += 2) {
+                if (kl + 2 < KH) {               // the next pair's gather stays in flight
                     gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, na);
                     gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, nb);
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-            if constexpr (WIENER) {
-                // Wiener holds two spectra (128 registers): no room to keep the next gather in
-                // flight across the transform; it is issued right after this pair has left a / b
-                // and overlaps the transform's LDS round trips and the partner wave instead.
-                if (kl + 1 < KH) {
-                    const size_t c0 = corner_of(kb + kl + 1);
-                    gather8(noisy + c0, sy, sz, hi, lo, a);
-                    gather8(basic + c0, sy, sz, hi, lo, b);
-                }
-            }
-            pair_fwd(T, tb, hi, lo, v2);
-            if constexpr (WIENER) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    S[j][2 * kl] = v2[j].x;
-                    S[j][2 * kl + 1] = v2[j].y;
-                }
-            } else {
+                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                pair_fwd(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
                 if (KH > 1) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
                 }
-            }
-            if constexpr (!WIENER) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     a[j] = na[j];
                     b[j] = nb[j];
+                }
+            }
+        } else if (KH == 1) {
+            const size_t c0 = corner_of(kb);
+            gather8(noisy + c0, sy, sz, hi, lo, a);
+            gather8(basic + c0, sy, sz, hi, lo, b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+            pair_fwd(T, tb, hi, lo, v2);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                S[j >> 1][j & 1] = v2[j].x;
+                SB[j >> 1][j & 1] = v2[j].y;
+            }
+        } else {
+            // two spectra (128 registers): no room for a second gather buffer; the next pair's
+            // gather is issued as soon as this pair has left a / b and overlaps the transform's
+            // LDS round trips and the SIMD's other wave
+            gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
+            gather8(noisy + corner_of(kb + 1), sy, sz, hi, lo, b);
+            for (int kl = 0; kl < KH; kl += 2) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                gather8(basic + corner_of(kb + kl), sy, sz, hi, lo, a);
+                gather8(basic + corner_of(kb + kl + 1), sy, sz, hi, lo, b);
+                pair_fwd(T, tb, hi, lo, v2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                    S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                if (kl + 2 < KH) {
+                    gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, a);
+                    gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, b);
+                }
+                pair_fwd(T, tb, hi, lo, v2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    SB[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                    SB[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
                 }
             }
         }
@@ -888,13 +906,13 @@ __device__ __forceinline__ bool process_half_group(
         // coefficients (hard threshold, as int bits) or the sum of squared Wiener weights.
         int nnz = 0;
         float sw = 0.0f;
-        f2 approx[NP];
+        f2 approx[NP];                 // Wiener: [0, 4) noisy plane pairs, [4, 8) basic plane pairs
         if constexpr (WIENER) {
             switch (KH) {
-                case 8: wiener_half_local<8>(S, sigma2, sw, approx); break;
-                case 4: wiener_half_local<4>(S, sigma2, sw, approx); break;
-                case 2: wiener_half_local<2>(S, sigma2, sw, approx); break;
-                default: wiener_half_local<1>(S, sigma2, sw, approx); break;
+                case 8: wiener_half_local<8>(S, SB, sigma2, sw, approx); break;
+                case 4: wiener_half_local<4>(S, SB, sigma2, sw, approx); break;
+                case 2: wiener_half_local<2>(S, SB, sigma2, sw, approx); break;
+                default: wiener_half_local<1>(S, SB, sigma2, sw, approx); break;
             }
         } else {
             switch (KH) {
@@ -904,7 +922,7 @@ __device__ __forceinline__ bool process_half_group(
                 default: half_shrink_local<1>(S, thr, nnz, approx); break;
             }
         }
-        float mine[8];                 // Wiener: filtered noisy approximation of my half, per plane
+        f2 top[4];                     // filtered approximation pairs of my half, per plane pair
         if (K > 1) {
             seq++;
             // my transpose buffer is free (forward transforms done; the partner acknowledged the
@@ -928,66 +946,75 @@ __device__ __forceinline__ bool process_half_group(
             else
                 nnz += __float_as_int(theirs);
 #pragma unroll
-            for (int jp = 0; jp < NP; jp++) {
+            for (int jp = 0; jp < 4; jp++) {
                 const f2 a0 = half ? other[jp] : approx[jp], a1 = half ? approx[jp] : other[jp];
                 f2 t0 = (a0 + a1) * HAAR_C, t1 = (a0 - a1) * HAAR_C;
                 if constexpr (WIENER) {
-                    const float e0 = t0.y * t0.y, e1 = t1.y * t1.y;
-                    const float W0 = e0 * __builtin_amdgcn_rcpf(e0 + sigma2);
-                    const float W1 = e1 * __builtin_amdgcn_rcpf(e1 + sigma2);
-                    sw += W0 * W0;
-                    sw += W1 * W1;
-                    const float f0 = W0 * t0.x, f1 = W1 * t1.x;
-                    mine[jp] = half ? (f0 - f1) * HAAR_C : (f0 + f1) * HAAR_C;
+                    const f2 b0 = half ? other[4 + jp] : approx[4 + jp];
+                    const f2 b1 = half ? approx[4 + jp] : other[4 + jp];
+                    const f2 u0 = (b0 + b1) * HAAR_C, u1 = (b0 - b1) * HAAR_C;
+                    const f2 e0 = u0 * u0, e1 = u1 * u1;
+                    const f2 d0 = e0 + sigma2, d1 = e1 + sigma2;
+                    const f2 W0 = e0 * mk2(__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y));
+                    const f2 W1 = e1 * mk2(__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y));
+                    sw += W0.x * W0.x;
+                    sw += W0.y * W0.y;
+                    sw += W1.x * W1.x;
+                    sw += W1.y * W1.y;
+                    t0 = W0 * t0;
+                    t1 = W1 * t1;
                 } else {
                     const bool p0 = fabsf(t0.x) >= thr, p1 = fabsf(t0.y) >= thr;
                     const bool q0 = fabsf(t1.x) >= thr, q1 = fabsf(t1.y) >= thr;
                     nnz += (p0 ? 1 : 0) + (p1 ? 1 : 0) + (q0 ? 1 : 0) + (q1 ? 1 : 0);
                     t0 = mk2(p0 ? t0.x : 0.0f, p1 ? t0.y : 0.0f);
                     t1 = mk2(q0 ? t1.x : 0.0f, q1 ? t1.y : 0.0f);
-                    approx[jp] = half ? (t0 - t1) * HAAR_C : (t0 + t1) * HAAR_C;
                 }
+                top[jp] = half ? (t0 - t1) * HAAR_C : (t0 + t1) * HAAR_C;
             }
         } else {
 #pragma unroll
-            for (int jp = 0; jp < NP; jp++) {
+            for (int jp = 0; jp < 4; jp++) {
                 if constexpr (WIENER) {
-                    const float e = approx[jp].y * approx[jp].y;
-                    const float W = e * __builtin_amdgcn_rcpf(e + sigma2);
-                    sw += W * W;
-                    mine[jp] = W * approx[jp].x;
+                    const f2 e = approx[4 + jp] * approx[4 + jp];
+                    const f2 d = e + sigma2;
+                    const f2 W = e * mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+                    sw += W.x * W.x;
+                    sw += W.y * W.y;
+                    top[jp] = W * approx[jp];
                 } else {
                     const bool p0 = fabsf(approx[jp].x) >= thr, p1 = fabsf(approx[jp].y) >= thr;
                     nnz += (p0 ? 1 : 0) + (p1 ? 1 : 0);
-                    approx[jp] = mk2(p0 ? approx[jp].x : 0.0f, p1 ? approx[jp].y : 0.0f);
+                    top[jp] = mk2(p0 ? approx[jp].x : 0.0f, p1 ? approx[jp].y : 0.0f);
                 }
             }
         }
+        switch (KH) {
+            case 8: half_unshrink_local<8>(S, top); break;
+            case 4: half_unshrink_local<4>(S, top); break;
+            case 2: half_unshrink_local<2>(S, top); break;
+            default: half_unshrink_local<1>(S, top); break;
+        }
         float w;
         if constexpr (WIENER) {
-            switch (KH) {
-                case 8: wiener_half_unlocal<8>(S, mine); break;
-                case 4: wiener_half_unlocal<4>(S, mine); break;
-                case 2: wiener_half_unlocal<2>(S, mine); break;
-                default: wiener_half_unlocal<1>(S, mine); break;
-            }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
             w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
         } else {
-            switch (KH) {
-                case 8: half_unshrink_local<8>(S, approx); break;
-                case 4: half_unshrink_local<4>(S, approx); break;
-                case 2: half_unshrink_local<2>(S, approx); break;
-                default: half_unshrink_local<1>(S, approx); break;
-            }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
             w = 1.0f / (sigma2 * (float)(nnz > 1 ? nnz : 1));
         }
         float ww[8];
+        if constexpr (WIENER) {
+            // the Wiener kernel has no registers to spare for the window between groups: its 8
+            // values per lane are re-read here (2 KB table, L1-resident)
 #pragma unroll
-        for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+            for (int y = 0; y < 8; y++) ww[y] = w * win_g[(hi * 8 + y) * 8 + lo];
+        } else {
+#pragma unroll
+            for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+        }
         // denominator: this half's blocks put their weight onto their corners (see above)
         if (lane >= kb && lane < kb + KH) atomicAdd(cvol + (size_t)my_corner, w);
 
@@ -1009,12 +1036,8 @@ __device__ __forceinline__ bool process_half_group(
         for (int kl = 0; kl < KH; kl += 2) {
             const int kl2 = (kl + 1 < KH) ? kl + 1 : kl;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if constexpr (WIENER)
-                    v2[j] = mk2(S[j][2 * kl], S[j][2 * kl2]);
-                else
-                    v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
-            }
+            for (int j = 0; j < 8; j++)
+                v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
             pair_inv(T, tb, hi, lo, v2);
             int slot_a = __builtin_amdgcn_readlane(my_slot0, kb + kl) + hi;
             slot_a -= slot_a >= HNPL ? HNPL : 0;
@@ -1059,10 +1082,15 @@ __device__ __forceinline__ bool process_half_group(
     return __builtin_amdgcn_readfirstlane(closer) != 0;
 }
 
+#if EXABM4D_MFMA_DCT
+typedef DctTable HalfTable;
+#else
+typedef Dct7 HalfTable;       // seven scalars instead of a 64-entry table in SGPRs (dct_pairs.h)
+#endif
 template <bool WIENER>
 __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
-    const uint32_t* __restrict__ keys_all, VolGeom g, DctTable T, const float* __restrict__ win_g,
+    const uint32_t* __restrict__ keys_all, VolGeom g, HalfTable T, const float* __restrict__ win_g,
     float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x,
     int layers_per_chunk) {
     extern __shared__ __align__(16) float lds[];
@@ -1100,8 +1128,8 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     // lock[1] = layers retired (in order); the ring itself needs no lock (fp64 LDS atomics)
     if (threadIdx.x < 4 + 2 * HNW + HNCNT) lock[threadIdx.x] = 0;
 
-    float win[8];
-    {
+    float win[8] = {};
+    if constexpr (!WIENER) {
         const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
         for (int y = 0; y < 8; y++) win[y] = win_g[(hi * 8 + y) * 8 + lo];
@@ -1111,9 +1139,13 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     const int pairid = wave >> 1;
     int seq = 0;
     // 8-point transforms on the matrix pipe (dct_pairs.h) where the registers allow it
+#if EXABM4D_MFMA_DCT
     constexpr bool ON_MFMA = WIENER ? (EXABM4D_MFMA_DCT >= 2) : (EXABM4D_MFMA_DCT >= 1);
     const DctLane TL = ON_MFMA ? make_dct_lane(T, lane) : DctLane{};
     const auto& tab = pick_table<ON_MFMA>(T, TL);
+#else
+    const Dct7& tab = T;
+#endif
 #ifdef EXABM4D_STAMPS
     unsigned long long st[16] = {};
     const unsigned long long tk0 = stamp();
@@ -1142,7 +1174,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
             }
 #endif
             const bool closer = process_half_group<WIENER>(
-                noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, thr, sigma2, ring, cvol, tb,
+                noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, ring, cvol, tb,
                 partner_tb, lock, sync, cnt, wave, seq, layer, 2 * nrefs, lane
 #ifdef EXABM4D_STAMPS
                 , st
@@ -1223,18 +1255,24 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         hchunks = (g.gz + hlpc - 1) / hlpc;
         const dim3 hgrid((unsigned)(hty * tiles_x), (unsigned)hchunks, (unsigned)batch);
         const size_t lds = sizeof(float) * (2 * HNPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW + HNCNT);
+#if EXABM4D_MFMA_DCT
+        const DctTable& HT = T;
+#else
+        Dct7 HT;
+        if (!make_dct7(T, HT)) return hipErrorInvalidValue;    // the table lost its symmetry
+#endif
         if (basic) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(stage_half_kernel<true>, hgrid, dim3(HNW * 64), lds, stream, noisy, basic,
-                               keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
+                               keys, g, HT, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
         } else {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(stage_half_kernel<false>, hgrid, dim3(HNW * 64), lds, stream, noisy,
-                               basic, keys, g, T, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
+                               basic, keys, g, HT, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
