@@ -635,10 +635,16 @@ __device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLa
     else
         return T;
 }
-constexpr int HTY = 3;                         // grid points per tile in y (x keeps TILE_R = 4)
-constexpr int HROWS = (HTY - 1) * STEP + 18;  // 26 region rows
-constexpr int HPS = 808;                      // plane stride in elements: 780 padded to 8 (mod 32)
-constexpr int HNPL = 18;                      // ring planes
+#ifndef EXABM4D_HTY
+#define EXABM4D_HTY 2
+#endif
+#ifndef EXABM4D_HNPL
+#define EXABM4D_HNPL 22
+#endif
+constexpr int HTY = EXABM4D_HTY;               // grid points per tile in y (x keeps TILE_R = 4)
+constexpr int HROWS = (HTY - 1) * STEP + 18;  // region rows: 22 (26 for 3 points)
+constexpr int HPS = ((HROWS * REG + 23) / 32) * 32 + 8;   // plane stride in elements, 8 (mod 32): 680 (808)
+constexpr int HNPL = EXABM4D_HNPL;            // ring planes: 18 + 4 per layer a wave may run ahead of the flush
 constexpr int HGATE = (HNPL - 18) / STEP;     // extra layers of planes: a layer waits for the flush
                                               // of layer - 1 - HGATE
 constexpr int HNCNT = 8;                      // per-layer report counters
