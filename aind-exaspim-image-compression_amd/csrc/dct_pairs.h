@@ -291,6 +291,69 @@ __device__ __forceinline__ void pair_fwd(const TableT& T, f2* tb, int hi, int lo
     dct8_fwd2(T, v);                                             // along z
 }
 
+// Two block pairs through ONE transpose buffer, interleaved: while pair A's transposed data is on
+// its way back from LDS, pair B's arithmetic runs, and vice versa.  LDS executes a wave's
+// instructions in issue order, so B's writes (issued after A's reads) cannot overtake them and
+// one buffer serves both; the compiler fences only pin the order of the LDS accesses.
+template <typename TableT>
+__device__ __forceinline__ void pair_fwd_x2(const TableT& T, f2* tb, int hi, int lo, f2 (&a)[8], f2 (&b)[8]) {
+    dct8_fwd2(T, a);                                             // A along y
+#pragma unroll
+    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = a[y];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, a);                         // A -> L2 (in flight)
+    cbar();
+    dct8_fwd2(T, b);                                             // B along y
+#pragma unroll
+    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = b[y];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, b);                         // B -> L2 (in flight)
+    cbar();
+    dct8_fwd2(T, a);                                             // A along x
+#pragma unroll
+    for (int x = 0; x < 8; x++) tb[x * TSI + lo * TSJ + hi] = a[x];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, a);                         // A -> L3
+    cbar();
+    dct8_fwd2(T, b);                                             // B along x
+#pragma unroll
+    for (int x = 0; x < 8; x++) tb[x * TSI + lo * TSJ + hi] = b[x];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, b);                         // B -> L3
+    cbar();
+    dct8_fwd2(T, a);                                             // A along z
+    dct8_fwd2(T, b);                                             // B along z
+}
+template <typename TableT>
+__device__ __forceinline__ void pair_inv_x2(const TableT& T, f2* tb, int hi, int lo, f2 (&a)[8], f2 (&b)[8]) {
+    dct8_inv2(T, a);                                             // A along z
+#pragma unroll
+    for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = a[z];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, a);
+    cbar();
+    dct8_inv2(T, b);                                             // B along z
+#pragma unroll
+    for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = b[z];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, b);
+    cbar();
+    dct8_inv2(T, a);                                             // A along x
+#pragma unroll
+    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = a[x];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, a);
+    cbar();
+    dct8_inv2(T, b);                                             // B along x
+#pragma unroll
+    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = b[x];
+    cbar();
+    load8p(tb + hi * TSI + lo * TSJ, b);
+    cbar();
+    dct8_inv2(T, a);                                             // A along y
+    dct8_inv2(T, b);                                             // B along y
+}
+
 // Inverse of pair_fwd: L3 spectra in, spatial blocks in layout L1 out.
 template <typename TableT>
 __device__ __forceinline__ void pair_inv(const TableT& T, f2* tb, int hi, int lo, f2 (&v)[8]) {

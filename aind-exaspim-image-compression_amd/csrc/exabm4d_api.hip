@@ -317,6 +317,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->stage_pairs = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "stage_chunks") == 0) {       // diagnostic: z chunks of the stage kernels
+        g_stage_chunks = value > 0 ? value : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "chunk_budget_mb") == 0) {
         if (value < 1) return fail(ctx, EXABM4D_ERR_INVALID, "chunk_budget_mb must be >= 1");
         ctx->chunk_budget_mb = value;

@@ -58,6 +58,7 @@ hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny
                          double C1, double C2, double* partials, double* out1, hipStream_t s);
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded);
+extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chunk count (0 = automatic)
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,

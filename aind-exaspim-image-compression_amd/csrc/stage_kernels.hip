@@ -19,6 +19,7 @@
 // All DCT arithmetic is the even/odd-folded 4-term fmaf chain of DESIGN.md 3.5 and is
 // bit-identical to the oracle; only the order of the atomic sums differs.
 #include <algorithm>
+#include <type_traits>
 
 #include "exabm4d_kernels.h"
 #include "dct_pairs.h"
@@ -125,7 +126,12 @@ __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy
                                         int lo, float (&v)[8]) {
     // uniform row base (SGPR pair) + one 32-bit lane offset: global_load with saddr, no 64-bit
     // VALU address arithmetic per row (make_geom guarantees 7 planes fit 32-bit byte offsets)
+#ifdef EXABM4D_FAKE_GATHER
+    // timing probe only (wrong results): every instruction reads one contiguous 256-byte piece
+    const unsigned loff = (unsigned)(hi * 8 + lo);
+#else
     const unsigned loff = (unsigned)hi * (unsigned)sz + (unsigned)lo;
+#endif
 #pragma unroll
     for (int y = 0; y < 8; y++) v[y] = (src + (size_t)y * sy)[loff];
 }
@@ -635,6 +641,9 @@ __device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLa
     else
         return T;
 }
+#ifndef EXABM4D_X2
+#define EXABM4D_X2 1                           // 0: one block pair per transform everywhere (A/B builds)
+#endif
 #ifndef EXABM4D_HTY
 #define EXABM4D_HTY 2
 #endif
@@ -810,7 +819,12 @@ __device__ __forceinline__ bool process_half_group(
     const bool active = K > 1 || half == 0;    // a one-block group is the first wave's alone
 
     int closer = 0;
-    if (active) {
+    // The body of an active half, as a generic lambda over the half's block count: with KH a
+    // compile-time constant every loop over blocks unrolls and every access to the spectrum has a
+    // constant register index.  (With a run-time KH each element went through s_set_gpr_idx_on /
+    // v_mov / s_set_gpr_idx_off: three instructions per moved float, a fifth of the kernel.)
+    auto body = [&](auto KHc) {
+        constexpr int KH = decltype(KHc)::value;
         f16v S[4];                             // (noisy) spectrum of my blocks
         f16v SB[WIENER ? 4 : 1];               // Wiener: basic-estimate spectrum, dead after the local step
 #pragma unroll
@@ -834,34 +848,59 @@ __device__ __forceinline__ bool process_half_group(
         };
         // Forward transforms of my blocks, two streams per transform: blocks (kl, kl + 1) of one
         // volume (a half of one block pairs the noisy block with the basic one in the Wiener
-        // stage, and runs the block twice in the hard-threshold stage).
+        // stage, and runs the block twice in the hard-threshold stage).  The next gather is
+        // issued as soon as the current values have left a / b (/ c / d).
         float a[8], b[8];
         f2 v2[8];
-        if constexpr (!WIENER) {
-            float na[8] = {}, nb[8] = {};
+        if constexpr (!WIENER && KH >= 4 && EXABM4D_X2) {
+            float c[8], d[8];
+            f2 w2[8];
+            gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
+            gather8(noisy + corner_of(kb + 1), sy, sz, hi, lo, b);
+            gather8(noisy + corner_of(kb + 2), sy, sz, hi, lo, c);
+            gather8(noisy + corner_of(kb + 3), sy, sz, hi, lo, d);
+#pragma unroll
+            for (int kl = 0; kl < KH; kl += 4) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    v2[j] = mk2(a[j], b[j]);
+                    w2[j] = mk2(c[j], d[j]);
+                }
+                if (kl + 4 < KH) {
+                    gather8(noisy + corner_of(kb + kl + 4), sy, sz, hi, lo, a);
+                    gather8(noisy + corner_of(kb + kl + 5), sy, sz, hi, lo, b);
+                    gather8(noisy + corner_of(kb + kl + 6), sy, sz, hi, lo, c);
+                    gather8(noisy + corner_of(kb + kl + 7), sy, sz, hi, lo, d);
+                }
+                pair_fwd_x2(T, tb, hi, lo, v2, w2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                    S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
+                    S[j >> 1][2 * kl + 4 + (j & 1)] = w2[j].x;
+                    S[j >> 1][2 * kl + 6 + (j & 1)] = w2[j].y;
+                }
+            }
+        } else if constexpr (!WIENER) {
             gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
             gather8(noisy + corner_of(kb + (KH > 1 ? 1 : 0)), sy, sz, hi, lo, b);
+#pragma unroll
             for (int kl = 0; kl < KH; kl += 2) {
-                if (kl + 2 < KH) {               // the next pair's gather stays in flight
-                    gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, na);
-                    gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, nb);
-                }
 #pragma unroll
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                if (kl + 2 < KH) {
+                    gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, a);
+                    gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, b);
+                }
                 pair_fwd(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
-                if (KH > 1) {
+                if constexpr (KH > 1) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
                 }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    a[j] = na[j];
-                    b[j] = nb[j];
-                }
             }
-        } else if (KH == 1) {
+        } else if constexpr (KH == 1) {
             const size_t c0 = corner_of(kb);
             gather8(noisy + c0, sy, sz, hi, lo, a);
             gather8(basic + c0, sy, sz, hi, lo, b);
@@ -874,11 +913,9 @@ __device__ __forceinline__ bool process_half_group(
                 SB[j >> 1][j & 1] = v2[j].y;
             }
         } else {
-            // two spectra (128 registers): no room for a second gather buffer; the next pair's
-            // gather is issued as soon as this pair has left a / b and overlaps the transform's
-            // LDS round trips and the SIMD's other wave
             gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
             gather8(noisy + corner_of(kb + 1), sy, sz, hi, lo, b);
+#pragma unroll
             for (int kl = 0; kl < KH; kl += 2) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
@@ -913,21 +950,10 @@ __device__ __forceinline__ bool process_half_group(
         int nnz = 0;
         float sw = 0.0f;
         f2 approx[NP];                 // Wiener: [0, 4) noisy plane pairs, [4, 8) basic plane pairs
-        if constexpr (WIENER) {
-            switch (KH) {
-                case 8: wiener_half_local<8>(S, SB, sigma2, sw, approx); break;
-                case 4: wiener_half_local<4>(S, SB, sigma2, sw, approx); break;
-                case 2: wiener_half_local<2>(S, SB, sigma2, sw, approx); break;
-                default: wiener_half_local<1>(S, SB, sigma2, sw, approx); break;
-            }
-        } else {
-            switch (KH) {
-                case 8: half_shrink_local<8>(S, thr, nnz, approx); break;
-                case 4: half_shrink_local<4>(S, thr, nnz, approx); break;
-                case 2: half_shrink_local<2>(S, thr, nnz, approx); break;
-                default: half_shrink_local<1>(S, thr, nnz, approx); break;
-            }
-        }
+        if constexpr (WIENER)
+            wiener_half_local<KH>(S, SB, sigma2, sw, approx);
+        else
+            half_shrink_local<KH>(S, thr, nnz, approx);
         f2 top[4];                     // filtered approximation pairs of my half, per plane pair
         if (K > 1) {
             seq++;
@@ -995,12 +1021,7 @@ __device__ __forceinline__ bool process_half_group(
                 }
             }
         }
-        switch (KH) {
-            case 8: half_unshrink_local<8>(S, top); break;
-            case 4: half_unshrink_local<4>(S, top); break;
-            case 2: half_unshrink_local<2>(S, top); break;
-            default: half_unshrink_local<1>(S, top); break;
-        }
+        half_unshrink_local<KH>(S, top);
         float w;
         if constexpr (WIENER) {
 #pragma unroll
@@ -1039,8 +1060,10 @@ __device__ __forceinline__ bool process_half_group(
         }
         STAMP(t3);
         STAMP_ADD(5, t2, t3);
+#pragma unroll
         for (int kl = 0; kl < KH; kl += 2) {
-            const int kl2 = (kl + 1 < KH) ? kl + 1 : kl;
+            constexpr bool two = KH > 1;
+            const int kl2 = two ? kl + 1 : kl;
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
@@ -1058,7 +1081,7 @@ __device__ __forceinline__ bool process_half_group(
             for (int y = 0; y < 8; y++)
                 __hip_atomic_fetch_add(ring + off_a + y * REG, (double)(ww[y] * v2[y].x), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (kl2 != kl) {
+            if constexpr (two) {
 #pragma unroll
                 for (int y = 0; y < 8; y++)
                     __hip_atomic_fetch_add(ring + off_b + y * REG, (double)(ww[y] * v2[y].y),
@@ -1066,6 +1089,14 @@ __device__ __forceinline__ bool process_half_group(
             }
             STAMP(tl2);
             STAMP_ADD(4, tl1, tl2);
+        }
+    };
+    if (active) {
+        switch (KH) {
+            case 8: body(std::integral_constant<int, 8>{}); break;
+            case 4: body(std::integral_constant<int, 4>{}); break;
+            case 2: body(std::integral_constant<int, 2>{}); break;
+            default: body(std::integral_constant<int, 1>{}); break;
         }
     }
     if (!active) {
@@ -1222,6 +1253,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 
 constexpr int NW_HT = 4;
 constexpr int NW_WIE = 4;
+int g_stage_chunks = 0;      // exabm4d_set_option("stage_chunks"): z chunks of the stage kernels, 0 = automatic
 
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
@@ -1255,6 +1287,7 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         int hchunks = (int)((1024 + htiles - 1) / htiles);
         const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
         if (hchunks < fine) hchunks = fine;
+        if (g_stage_chunks > 0) hchunks = g_stage_chunks;
         if (hchunks < 1) hchunks = 1;
         if (hchunks > g.gz) hchunks = g.gz;
         const int hlpc = (g.gz + hchunks - 1) / hchunks;

@@ -286,6 +286,8 @@ def main():
         ctx.record(ev[3])
 
     ctx.set_option("profile", 1)
+    if os.environ.get("EXABM4D_STAGE_CHUNKS"):           # diagnostic sweep (tools/dbg)
+        ctx.set_option("stage_chunks", int(os.environ["EXABM4D_STAGE_CHUNKS"]))
     for _ in range(args.warmup):
         step()
     barrier()

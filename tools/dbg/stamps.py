@@ -6,7 +6,7 @@ from aind_exaspim_image_compression import _native as nat
 import bench
 ctx = nat.context(0)
 ctx.set_option("stage_pairs", int(os.environ.get("PAIRS", "1")))
-shape = (256,)*3
+shape = (int(os.environ.get("SIZE", "512")),)*3
 vol = bench.synth_u16(shape, 1000)
 d_in = ctx.to_device(vol); d_out = ctx.alloc(vol.nbytes)
 L = ctypes.CDLL(os.environ["EXABM4D_LIB"])
