@@ -112,8 +112,8 @@ static int make_geom(exabm4d_ctx* ctx, int nz, int ny, int nx, int batch, VolGeo
     g.nvox = (long long)nz * ny * nx;
     g.nref = (long long)g.gz * g.gy * g.gx;
     if (g.nref > 0x7FFFFFFFLL) return fail(ctx, EXABM4D_ERR_INVALID, "volume too large for one launch");
-    if ((long long)ny * nx * 8 * 4 > 0xFFFFFFFFLL)
-        return fail(ctx, EXABM4D_ERR_INVALID, "z-plane too large (8 planes must fit 32-bit byte offsets)");
+    if ((long long)ny * nx * 24 * 4 > 0xFFFFFFFFLL)
+        return fail(ctx, EXABM4D_ERR_INVALID, "z-plane too large (24 planes must fit 32-bit byte offsets)");
     return EXABM4D_OK;
 }
 static uint32_t keymax_of(float sigma, float c_match) {

@@ -136,6 +136,21 @@ __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy
     for (int y = 0; y < 8; y++) v[y] = (src + (size_t)y * sy)[loff];
 }
 
+// The same with the lane's eight row offsets (hi * sz + y * sy + lo, constant for the whole
+// kernel) precomputed in registers: one uniform base per block (the corner) in an SGPR pair and no
+// scalar address arithmetic per row -- the unrolled half-group bodies otherwise hold 16 SGPRs of
+// row bases per block in flight and spill scalars into vector lanes.
+// Buffer loads: the volume window of a group (planes rz - 5 ...) behind one 128-bit descriptor,
+// the block's corner as the scalar offset, the lane's row as the 32-bit vector offset -- no 64-bit
+// address arithmetic at all (hipcc does not form the global_load saddr + voffset variant here and
+// spends a v_lshl_add_u64 per row otherwise).  Out-of-range offsets would read 0, not fault.
+__device__ __forceinline__ void gather8v(__amdgpu_buffer_rsrc_t rsrc, int corner, const unsigned (&voff)[8],
+                                         float (&v)[8]) {
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+        v[y] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[y], corner, 0));
+}
+
 typedef float f32v __attribute__((ext_vector_type(32)));
 
 // Packed Haar along the group axis: v[k] holds two independent sequences in .x / .y.
@@ -801,7 +816,8 @@ __device__ __forceinline__ bool process_half_group(
     int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
     const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, ring_t* ring,
     float* __restrict__ cvol, f2* tb,
-    f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane
+    f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane,
+    long long g_nvox
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
 #endif
@@ -840,25 +856,35 @@ __device__ __forceinline__ bool process_half_group(
             lane < MAXG ? (unsigned long long)(rz + my_dz) * sz +
                               (unsigned long long)(ry + my_dy) * sy + (unsigned long long)(rx + my_dx)
                         : 0ull;
-        const unsigned my_corner_lo = (unsigned)my_corner, my_corner_hi = (unsigned)(my_corner >> 32);
-        auto corner_of = [&](int k) -> size_t {
-            const unsigned lo32 = __builtin_amdgcn_readlane(my_corner_lo, k);
-            const unsigned hi32 = __builtin_amdgcn_readlane(my_corner_hi, k);
-            return ((size_t)hi32 << 32) | lo32;
-        };
+        // buffer descriptors of the group's window: planes zb .. (blocks start at rz - 5 at the
+        // lowest), byte offsets inside it fit 32 bits (make_geom: 24 planes do)
+        const int zb = max(rz - RAD, 0);
+        const size_t win_off = (size_t)zb * sz;
+        const size_t win_left = (size_t)g_nvox - win_off;
+        const int win_bytes = (int)min(win_left * sizeof(float), (size_t)0x7FFFFFFFu * 2u);
+        const __amdgpu_buffer_rsrc_t noisy_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(noisy + win_off), 0, win_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t basic_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>((WIENER ? basic : noisy) + win_off), 0, win_bytes, 0x00020000);
+        const int my_rel = lane < MAXG ? (int)(4u * (unsigned)(my_corner - win_off)) : 0;
+        auto corner_of = [&](int k) -> int { return __builtin_amdgcn_readlane(my_rel, k); };
         // Forward transforms of my blocks, two streams per transform: blocks (kl, kl + 1) of one
         // volume (a half of one block pairs the noisy block with the basic one in the Wiener
         // stage, and runs the block twice in the hard-threshold stage).  The next gather is
         // issued as soon as the current values have left a / b (/ c / d).
         float a[8], b[8];
         f2 v2[8];
+        unsigned voff[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+            voff[y] = 4u * ((unsigned)hi * (unsigned)sz + (unsigned)y * (unsigned)sy + (unsigned)lo);
         if constexpr (!WIENER && KH >= 4 && EXABM4D_X2) {
             float c[8], d[8];
             f2 w2[8];
-            gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
-            gather8(noisy + corner_of(kb + 1), sy, sz, hi, lo, b);
-            gather8(noisy + corner_of(kb + 2), sy, sz, hi, lo, c);
-            gather8(noisy + corner_of(kb + 3), sy, sz, hi, lo, d);
+            gather8v(noisy_r, corner_of(kb), voff, a);
+            gather8v(noisy_r, corner_of(kb + 1), voff, b);
+            gather8v(noisy_r, corner_of(kb + 2), voff, c);
+            gather8v(noisy_r, corner_of(kb + 3), voff, d);
 #pragma unroll
             for (int kl = 0; kl < KH; kl += 4) {
 #pragma unroll
@@ -867,10 +893,10 @@ __device__ __forceinline__ bool process_half_group(
                     w2[j] = mk2(c[j], d[j]);
                 }
                 if (kl + 4 < KH) {
-                    gather8(noisy + corner_of(kb + kl + 4), sy, sz, hi, lo, a);
-                    gather8(noisy + corner_of(kb + kl + 5), sy, sz, hi, lo, b);
-                    gather8(noisy + corner_of(kb + kl + 6), sy, sz, hi, lo, c);
-                    gather8(noisy + corner_of(kb + kl + 7), sy, sz, hi, lo, d);
+                    gather8v(noisy_r, corner_of(kb + kl + 4), voff, a);
+                    gather8v(noisy_r, corner_of(kb + kl + 5), voff, b);
+                    gather8v(noisy_r, corner_of(kb + kl + 6), voff, c);
+                    gather8v(noisy_r, corner_of(kb + kl + 7), voff, d);
                 }
                 pair_fwd_x2(T, tb, hi, lo, v2, w2);
 #pragma unroll
@@ -882,15 +908,15 @@ __device__ __forceinline__ bool process_half_group(
                 }
             }
         } else if constexpr (!WIENER) {
-            gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
-            gather8(noisy + corner_of(kb + (KH > 1 ? 1 : 0)), sy, sz, hi, lo, b);
+            gather8v(noisy_r, corner_of(kb), voff, a);
+            gather8v(noisy_r, corner_of(kb + (KH > 1 ? 1 : 0)), voff, b);
 #pragma unroll
             for (int kl = 0; kl < KH; kl += 2) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
                 if (kl + 2 < KH) {
-                    gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, a);
-                    gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, b);
+                    gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
+                    gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
                 }
                 pair_fwd(T, tb, hi, lo, v2);
 #pragma unroll
@@ -902,8 +928,8 @@ __device__ __forceinline__ bool process_half_group(
             }
         } else if constexpr (KH == 1) {
             const size_t c0 = corner_of(kb);
-            gather8(noisy + c0, sy, sz, hi, lo, a);
-            gather8(basic + c0, sy, sz, hi, lo, b);
+            gather8v(noisy_r, c0, voff, a);
+            gather8v(basic_r, c0, voff, b);
 #pragma unroll
             for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
             pair_fwd(T, tb, hi, lo, v2);
@@ -913,14 +939,14 @@ __device__ __forceinline__ bool process_half_group(
                 SB[j >> 1][j & 1] = v2[j].y;
             }
         } else {
-            gather8(noisy + corner_of(kb), sy, sz, hi, lo, a);
-            gather8(noisy + corner_of(kb + 1), sy, sz, hi, lo, b);
+            gather8v(noisy_r, corner_of(kb), voff, a);
+            gather8v(noisy_r, corner_of(kb + 1), voff, b);
 #pragma unroll
             for (int kl = 0; kl < KH; kl += 2) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-                gather8(basic + corner_of(kb + kl), sy, sz, hi, lo, a);
-                gather8(basic + corner_of(kb + kl + 1), sy, sz, hi, lo, b);
+                gather8v(basic_r, corner_of(kb + kl), voff, a);
+                gather8v(basic_r, corner_of(kb + kl + 1), voff, b);
                 pair_fwd(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
@@ -930,8 +956,8 @@ __device__ __forceinline__ bool process_half_group(
 #pragma unroll
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
                 if (kl + 2 < KH) {
-                    gather8(noisy + corner_of(kb + kl + 2), sy, sz, hi, lo, a);
-                    gather8(noisy + corner_of(kb + kl + 3), sy, sz, hi, lo, b);
+                    gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
+                    gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
                 }
                 pair_fwd(T, tb, hi, lo, v2);
 #pragma unroll
@@ -1212,7 +1238,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 #endif
             const bool closer = process_half_group<WIENER>(
                 noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, ring, cvol, tb,
-                partner_tb, lock, sync, cnt, wave, seq, layer, 2 * nrefs, lane
+                partner_tb, lock, sync, cnt, wave, seq, layer, 2 * nrefs, lane, g.nvox
 #ifdef EXABM4D_STAMPS
                 , st
 #endif

@@ -5,7 +5,7 @@
 set -e
 name=$1; shift
 here=$(cd "$(dirname "$0")" && pwd)
-src=$here/../../aind-exaspim-image-compression_amd/csrc
+src=${SRC:-$here/../../aind-exaspim-image-compression_amd/csrc}
 out=$here/variants
 mkdir -p "$out/obj_$name"
 flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off"
