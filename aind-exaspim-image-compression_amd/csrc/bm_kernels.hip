@@ -111,11 +111,31 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // LDS-DMA of one plane into buffer `dst`: instruction i writes floats [256 i, 256 i + 256)
     // linearly, lane l the 16 bytes at chunk p = 64 i + l = (row p / 14, column chunk p % 14);
     // chunks beyond column 10 or row 36 are padding and re-read a valid address.
+    // Tiles whose staged rows all lie inside the volume in y (all but the first and last tile row):
+    // the row of a chunk needs no clamp, so its source is a wave-uniform base (plane, first row,
+    // first column) plus a lane constant r * sy + 4 q -- eight instructions per DMA instead of the
+    // thirty of the clamped form (a fifth of a step's instructions went into these addresses).
+    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
     auto issue_dma = [&](int step, float* dst) {
         int dylo;
         const float* plane = step_plane(step, dylo);
         int l = lane;
         asm volatile("" : "+v"(l));          // keeps the 9 (row, column) pairs out of registers
+        if (yin) {
+            const float* base = plane + (ptrdiff_t)(Y0 + dylo) * (ptrdiff_t)sy + X0;
+#pragma unroll
+            for (int i = 0; i < NDMA; i++) {
+                const unsigned p = 64u * i + (unsigned)l;
+                const unsigned r0 = (p * (65536u / PCH + 1u)) >> 16;          // p / PCH for p < 2^12
+                const unsigned r = min(r0, (unsigned)(PROWS - 1));
+                const unsigned q = min(p - r0 * PCH, (unsigned)(PCOLS / 4 - 1));
+                const float* src = base + (r * (unsigned)sy + 4u * q);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)src,
+                    (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NDMA; i++) {
             const int p = 64 * i + l;
