@@ -659,6 +659,9 @@ __device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLa
 #ifndef EXABM4D_X2
 #define EXABM4D_X2 1                           // 0: one block pair per transform everywhere (A/B builds)
 #endif
+#ifndef EXABM4D_X2INV
+#define EXABM4D_X2INV 1                        // inverse transforms of four blocks as two interleaved pairs
+#endif
 #ifndef EXABM4D_HTY
 #define EXABM4D_HTY 2
 #endif
@@ -1086,35 +1089,52 @@ __device__ __forceinline__ bool process_half_group(
         }
         STAMP(t3);
         STAMP_ADD(5, t2, t3);
-#pragma unroll
-        for (int kl = 0; kl < KH; kl += 2) {
-            constexpr bool two = KH > 1;
-            const int kl2 = two ? kl + 1 : kl;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
-            pair_inv(T, tb, hi, lo, v2);
-            int slot_a = __builtin_amdgcn_readlane(my_slot0, kb + kl) + hi;
-            slot_a -= slot_a >= HNPL ? HNPL : 0;
-            const int off_a = slot_a * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl) + lo;
-            int slot_b = __builtin_amdgcn_readlane(my_slot0, kb + kl2) + hi;
-            slot_b -= slot_b >= HNPL ? HNPL : 0;
-            const int off_b = slot_b * HPS + __builtin_amdgcn_readlane(my_yx, kb + kl2) + lo;
-            STAMP(tl0);
-            STAMP(tl1);
-            // lock-free: fp64 LDS atomics, no return value, both blocks back to back
+        // ring offsets of a block: first plane slot of the lane's z, (y, x) offset of the lane's x
+        auto ring_off = [&](int k) -> int {
+            int slot = __builtin_amdgcn_readlane(my_slot0, k) + hi;
+            slot -= slot >= HNPL ? HNPL : 0;
+            return slot * HPS + __builtin_amdgcn_readlane(my_yx, k) + lo;
+        };
+        auto ring_add = [&](int off, const f2 (&v)[8], int comp) {
+            // lock-free: fp64 LDS atomics, no return value
 #pragma unroll
             for (int y = 0; y < 8; y++)
-                __hip_atomic_fetch_add(ring + off_a + y * REG, (double)(ww[y] * v2[y].x), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            if constexpr (two) {
+                __hip_atomic_fetch_add(ring + off + y * REG, (double)(ww[y] * (comp ? v[y].y : v[y].x)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if constexpr (KH >= 4 && EXABM4D_X2INV) {
+            f2 w2[8];
 #pragma unroll
-                for (int y = 0; y < 8; y++)
-                    __hip_atomic_fetch_add(ring + off_b + y * REG, (double)(ww[y] * v2[y].y),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int kl = 0; kl < KH; kl += 4) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl + 2 + (j & 1)]);
+                    w2[j] = mk2(S[j >> 1][2 * kl + 4 + (j & 1)], S[j >> 1][2 * kl + 6 + (j & 1)]);
+                }
+                pair_inv_x2(T, tb, hi, lo, v2, w2);
+                STAMP(tl1);
+                ring_add(ring_off(kb + kl), v2, 0);
+                ring_add(ring_off(kb + kl + 1), v2, 1);
+                ring_add(ring_off(kb + kl + 2), w2, 0);
+                ring_add(ring_off(kb + kl + 3), w2, 1);
+                STAMP(tl2);
+                STAMP_ADD(4, tl1, tl2);
             }
-            STAMP(tl2);
-            STAMP_ADD(4, tl1, tl2);
+        } else {
+#pragma unroll
+            for (int kl = 0; kl < KH; kl += 2) {
+                constexpr bool two = KH > 1;
+                const int kl2 = two ? kl + 1 : kl;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
+                pair_inv(T, tb, hi, lo, v2);
+                STAMP(tl1);
+                ring_add(ring_off(kb + kl), v2, 0);
+                if constexpr (two) ring_add(ring_off(kb + kl2), v2, 1);
+                STAMP(tl2);
+                STAMP_ADD(4, tl1, tl2);
+            }
         }
     };
     if (active) {
