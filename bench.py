@@ -20,8 +20,12 @@ N > 1 = one process per GPU (torch.distributed / RCCL for the barrier and the ma
 
 One JSON line is printed by rank 0.  `roofline` is for the dominant kernel, timed live with HIP
 events recorded on the stream the kernels run on (exabm4d "profile" option) inside the timed
-region.  `cpu_baseline` times the CPU oracle (a port: the reference's BM4D is a closed wheel that
-cannot travel) on a bounded sample on this box's host cores.
+region; its `traffic` and `valu` entries come from the committed rocprofv3 passes
+(profiles/latest_counters.json names the profile and the commit) and are flagged stale when the
+live kernel time has moved.  `cpu_baseline` times the CPU port (oracle/exabm4d_cpu_port.c; the
+reference's BM4D is a closed wheel that cannot travel) on this box's host cores: BASELINE configs
+C1 and C2 fully, all usable cores and one thread.  `bm4dnet` (config 3's learned stage) and
+`encoded` (compression ratios of the encode legs) are extra keys outside `value`.
 """
 import argparse
 import json
@@ -107,35 +111,127 @@ def synth_u16(shape, seed, z_range=None):
     return out
 
 
-def measured_traffic(kernel, shape):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/traffic_latest.json: FETCH_SIZE / WRITE_SIZE passes with the gfx950 correction),
-    or None when no profile of this volume shape is on file."""
+def profile_record(kernel, shape, live_ms):
+    """What the committed rocprofv3 passes say about `kernel` at this volume shape
+    (profiles/latest_counters.json, written by tools/pmc_summary.py from SEPARATE --pmc passes of
+    this same bench command; it names the profile directory and the commit that was profiled):
+    HBM bytes per launch (FETCH_SIZE / WRITE_SIZE with the gfx950 correction) and the VALU counters.
+    A record whose kernel time differs from the live one by more than 10 % is flagged stale."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "latest_counters.json")) as f:
             t = json.load(f)
-        if list(t["volume"]) == list(shape):
-            return t["bytes_per_launch"].get(kernel)
+        if list(t["volume"]) != list(shape):
+            return None
+        rec = dict(t["kernels"][kernel])
     except (OSError, ValueError, KeyError):
+        return None
+    rec["source"] = {"file": t.get("source"), "commit": t.get("commit")}
+    if rec.get("avg_ms"):
+        rec["stale"] = bool(abs(live_ms - rec["avg_ms"]) > 0.1 * rec["avg_ms"])
+    return rec
+
+
+def host_cpu():
+    """CPU model and the number of cores this process may actually use (affinity mask and cgroup
+    quota -- a GPU box hands a job a share of its cores, omp_get_max_threads still sees them all)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
         pass
-    return None
+    usable = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return model, usable, os.cpu_count()
 
 
-def cpu_baseline(sample_edge, seed):
-    """CPU oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
-    from oracle import bm4d_oracle
-    bm4d_oracle.build()
-    vol = synth_u16((sample_edge,) * 3, seed)
-    t0 = time.perf_counter()
-    bm4d_oracle.bm4d_u16(vol, SIGMA, OFFSET, stages=2)
-    dt = time.perf_counter() - t0
+def cpu_baseline(seed, budget_s=30.0):
+    """The CPU port (oracle/exabm4d_cpu_port.c: the specification of DESIGN.md 3 written for a
+    many-core host -- shared cell sums, SIMD over the dx candidates and the transform lines,
+    coloured parallel scatter; match tables bit-identical to the checker) on this box's host cores.
+    BASELINE.md section 3: configs C1 (64^3) and C2 (256^3) timed fully, all usable cores and one
+    thread (the 1-thread C2 leg is a 128^3 sample when the budget does not allow the full volume)."""
+    from oracle import bm4d_oracle as O
+    O.build()
+    model, usable, visible = host_cpu()
+
+    def timed(edge, threads, reps=1):
+        vol = synth_u16((edge,) * 3, seed)
+        O.set_threads(threads)
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.bm4d_u16(vol, SIGMA, OFFSET, stages=2, port=True)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return {"edge": edge, "threads": threads, "seconds": round(best, 3),
+                "voxels_per_s": vol.size / best}
+
+    t_start = time.perf_counter()
+    c1_all = timed(64, usable, reps=3)
+    c1_one = timed(64, 1)
+    c2_all = timed(256, usable)
+    est_one = c2_all["seconds"] * usable * 0.8            # optimistic guess of the 1-thread C2 time
+    left = budget_s - (time.perf_counter() - t_start)
+    c2_one = timed(256, 1) if est_one < left else timed(128, 1)
+    O.set_threads(usable)
     return {
-        "value": vol.size / dt,
+        "value": c2_all["voxels_per_s"],
         "unit": "voxels/s",
-        "cores": bm4d_oracle.num_threads(),
+        "cores": usable,
         "kind": "port",
-        "sample": f"{sample_edge}^3 uint16 synthetic sub-volume, two-stage BM4D, "
-                  f"C oracle with OpenMP, {dt:.1f} s",
+        "sample": f"256^3 uint16 synthetic volume (BASELINE config 2 size), two-stage BM4D, timed "
+                  f"fully: {c2_all['seconds']} s on {usable} threads",
+        "cpu_model": model,
+        "cpus_visible": visible,
+        "c1_64_all_threads": c1_all,
+        "c1_64_one_thread": c1_one,
+        "c2_256_all_threads": c2_all,
+        "one_thread_large": c2_one,
+    }
+
+
+def bm4dnet_leg(edge, seed):
+    """BASELINE config 3's learned stage: device-resident predict() of the BM4DNet U-Net (PyTorch-ROCm /
+    MIOpen only, per north_star; random-init weights -- throughput, not quality) on an edge^3
+    sub-volume; the 1024^3 figure is extrapolated by patch count (8000 patches) and says so."""
+    import torch
+    from aind_exaspim_image_compression import inference
+    from aind_exaspim_image_compression.machine_learning import transforms as T
+    from aind_exaspim_image_compression.machine_learning import unet3d
+    torch.manual_seed(0)
+    model = unet3d.UNet().cuda().eval()
+    tf = T.build_transform({"kind": "offset",
+                            "base": {"kind": "asinh", "params": {"offset": 0.0, "scale": 32.0}},
+                            "params": {"offset": OFFSET}})
+    vol = synth_u16((edge,) * 3, seed)
+    inference.predict(vol[:64, :64, :128], model, tf, batch_size=2, verbose=False)   # MIOpen warm-up
+    t0 = time.perf_counter()
+    inference.predict(vol, model, tf, batch_size=32, verbose=False)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    inference.predict(vol, model, tf, batch_size=32, verbose=False)
+    dt = time.perf_counter() - t0
+    npatch = inference.count_patches(inference._ShapeOnly((1, 1) + vol.shape), 64, 12)
+    return {
+        "what": f"inference.predict on a {edge}^3 uint16 sub-volume: asinh transform, {npatch} patches "
+                "of 64^3 (overlap 12, trim 5), batch 32, fp32 U-Net (12.9 M parameters, random init), "
+                "stitching and inverse transform on device, host to host",
+        "seconds": round(dt, 3),
+        "first_call_seconds": round(first, 3),
+        "voxels_per_s": vol.size / dt,
+        "unet_tflops": npatch * 109.639e9 / dt / 1e12,
+        "extrapolated_1024_seconds": round(dt * 8000.0 / npatch, 1),
+        "extrapolation": "8000 / %d patches x measured time (same batch shape); not measured at 1024^3" % npatch,
     }
 
 
@@ -213,8 +309,10 @@ def main():
                          "estimate between the two stages (distributed.py)")
     ap.add_argument("--no-encode", action="store_true",
                     help="time the denoiser alone (the metric's step includes the encode legs)")
-    ap.add_argument("--cpu-sample", type=int, default=128,
-                    help="edge of the CPU-baseline sample (0 disables the baseline)")
+    ap.add_argument("--cpu-sample", type=int, default=1,
+                    help="0 disables the CPU-baseline leg (C1 64^3 and C2 256^3 timed fully on the host)")
+    ap.add_argument("--bm4dnet", type=int, default=256,
+                    help="edge of the sub-volume of the BM4DNet (config 3) leg, reported as extra keys; 0 disables")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -334,6 +432,33 @@ def main():
         kern = {k: v for k, v in phase_avg.items() if k in ALGO_BYTES_PER_VOXEL}
         dom = max(kern, key=kern.get)
         achieved = ALGO_BYTES_PER_VOXEL[dom] * nvox / (kern[dom] * 1e-3) / 1e9
+        rec = profile_record(dom, shape, kern[dom]) or {}
+        roofline = {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": rec.get("hbm_bytes"),
+            "traffic_source": rec.get("source"),
+            "traffic_stale": rec.get("stale"),
+            "algorithmic_bytes_per_voxel": ALGO_BYTES_PER_VOXEL[dom],
+            "avg_ms": kern[dom],
+        }
+        if rec.get("valu_busy_cycles"):
+            # the kernel is compute-bound: its honest ceiling is the vector ALU, not HBM.  Busy
+            # cycles of the 1024 SIMDs (SQ_ACTIVE_INST_VALU, quad-cycles x 4) against the live
+            # kernel time at the 2.4 GHz peak clock (the chip clocks lower under load, so this
+            # fraction is a lower bound on the utilisation actually reached).
+            simd_cycles = 1024 * 2.4e9 * kern[dom] * 1e-3
+            roofline["valu"] = {
+                "bound": "valu_issue",
+                "insts_per_launch": rec.get("valu_insts"),
+                "busy_cycles_per_launch": rec["valu_busy_cycles"],
+                "peak_cycles": simd_cycles,
+                "frac": rec["valu_busy_cycles"] / simd_cycles,
+            }
         result = {
             "metric": "denoised+encoded voxels/s on 1024^3 uint16",
             "value": world * nvox * args.steps / elapsed,
@@ -360,24 +485,22 @@ def main():
                           f"(8^3 block DCT, q = {Q_STEP:g}, EXAC of the int32 indices)",
                 "sharding": "one independent volume per rank, no data-path collective",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dom,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(dom, shape),
-                "algorithmic_bytes_per_voxel": ALGO_BYTES_PER_VOXEL[dom],
-                "avg_ms": kern[dom],
-            },
+            "roofline": roofline,
             "phase_ms": phase_avg,
             "residual_std": resid_std,
         }
         if encoded is not None:
             result["encoded"] = encoded
         if args.cpu_sample > 0 and world == 1:         # reported baseline: rank 0 at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(args.cpu_sample, seed=1000)
+            result["cpu_baseline"] = cpu_baseline(seed=1000)
+        if args.bm4dnet > 0 and world == 1:
+            # BASELINE config 3's learned stage, after the timed region and outside `value`
+            for buf in (d_in, d_out):
+                buf.free()
+            try:
+                result["bm4dnet"] = bm4dnet_leg(args.bm4dnet, seed=1000)
+            except Exception as e:                    # the metric line must not die with the extra leg
+                result["bm4dnet"] = {"error": repr(e)}
         print(json.dumps(result), flush=True)
 
     if dist is not None:

@@ -21,7 +21,8 @@ KEY_EMPTY = 0xFFFFFFFF
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("exabm4d_oracle.c", "exac_codec.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("exabm4d_oracle.c", "exac_codec.c",
+                                             "exabm4d_cpu_port.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(map(os.path.getmtime, srcs)):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _SO
@@ -46,6 +47,8 @@ def lib():
         L.orc_keymax.restype = ctypes.c_uint32
         L.orc_blockmatch.argtypes = [f32p, c_int, c_int, c_int, c_f, c_f, u32p]
         L.orc_group_transform.argtypes = [f32p, c_int, c_int]
+        L.cpu_group_transform.argtypes = [f32p, c_int, c_int]
+        L.cpu_group_transform.restype = None
         L.orc_stage.argtypes = [f32p, f32p, u32p, c_int, c_int, c_int, c_f, c_f, c_d, f32p, f32p]
         L.orc_normalize.argtypes = [f32p, f32p, f32p, c_sz, c_f, c_f]
         L.orc_bm4d.argtypes = [f32p, f32p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_d, c_int,
@@ -57,6 +60,15 @@ def lib():
         L.orc_dctq_forward.restype = None
         L.orc_dctq_inverse.restype = None
         L.orc_num_threads.restype = c_int
+        L.orc_set_threads.argtypes = [c_int]
+        L.orc_set_threads.restype = None
+        # the CPU baseline port (oracle/exabm4d_cpu_port.c): same signatures as the oracle's
+        L.cpu_blockmatch.argtypes = L.orc_blockmatch.argtypes
+        L.cpu_stage.argtypes = L.orc_stage.argtypes
+        L.cpu_bm4d.argtypes = L.orc_bm4d.argtypes
+        L.cpu_bm4d_u16.argtypes = L.orc_bm4d_u16.argtypes
+        for name in ("cpu_blockmatch", "cpu_stage", "cpu_bm4d", "cpu_bm4d_u16"):
+            getattr(L, name).restype = None
         for name in ("orc_grid_positions", "orc_tables", "orc_blockmatch", "orc_group_transform",
                      "orc_stage", "orc_normalize", "orc_bm4d", "orc_bm4d_u16"):
             getattr(L, name).restype = None
@@ -74,6 +86,11 @@ def _f32(a):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def set_threads(n):
+    """omp_set_num_threads for the oracle / port library (bench.py's 1-thread and all-core legs)."""
+    lib().orc_set_threads(int(n))
 
 
 def grid_positions(n):
@@ -95,26 +112,28 @@ def keymax(sigma, c_match):
     return int(lib().orc_keymax(float(sigma), float(c_match)))
 
 
-def blockmatch(vol, sigma, c_match=DEFAULTS["c_match_ht"]):
-    """-> keys [gz,gy,gx,16] uint32."""
+def blockmatch(vol, sigma, c_match=DEFAULTS["c_match_ht"], port=False):
+    """-> keys [gz,gy,gx,16] uint32.  ``port``: the CPU baseline port instead of
+    the oracle (bit-identical tables)."""
     vol = _f32(vol)
     nz, ny, nx = vol.shape
     g = [len(grid_positions(n)) for n in (nz, ny, nx)]
     keys = np.empty((g[0], g[1], g[2], 16), dtype=np.uint32)
-    lib().orc_blockmatch(_p(vol, ctypes.c_float), nz, ny, nx, float(sigma), float(c_match),
-                         _p(keys, ctypes.c_uint32))
+    fn = lib().cpu_blockmatch if port else lib().orc_blockmatch
+    fn(_p(vol, ctypes.c_float), nz, ny, nx, float(sigma), float(c_match), _p(keys, ctypes.c_uint32))
     return keys
 
 
-def group_transform(g, inverse=False):
+def group_transform(g, inverse=False, port=False):
     """In-place-semantics 4-D transform of a [K,8,8,8] group; returns a new array."""
     g = _f32(g).copy()
-    lib().orc_group_transform(_p(g, ctypes.c_float), int(g.shape[0]), int(bool(inverse)))
+    fn = lib().cpu_group_transform if port else lib().orc_group_transform
+    fn(_p(g, ctypes.c_float), int(g.shape[0]), int(bool(inverse)))
     return g
 
 
 def stage(noisy, keys, sigma, basic=None, lambda_ht=DEFAULTS["lambda_ht"],
-          beta=DEFAULTS["kaiser_beta"]):
+          beta=DEFAULTS["kaiser_beta"], port=False):
     """-> (num, den) of one collaborative-filtering stage (hard-threshold if basic is None)."""
     noisy = _f32(noisy)
     nz, ny, nx = noisy.shape
@@ -125,9 +144,9 @@ def stage(noisy, keys, sigma, basic=None, lambda_ht=DEFAULTS["lambda_ht"],
     if basic is not None:
         basic = _f32(basic)
         bp = _p(basic, ctypes.c_float)
-    lib().orc_stage(_p(noisy, ctypes.c_float), bp, _p(keys, ctypes.c_uint32), nz, ny, nx,
-                    float(sigma), float(lambda_ht), float(beta), _p(num, ctypes.c_float),
-                    _p(den, ctypes.c_float))
+    fn = lib().cpu_stage if port else lib().orc_stage
+    fn(_p(noisy, ctypes.c_float), bp, _p(keys, ctypes.c_uint32), nz, ny, nx, float(sigma),
+       float(lambda_ht), float(beta), _p(num, ctypes.c_float), _p(den, ctypes.c_float))
     return num, den
 
 
@@ -153,12 +172,12 @@ def bm4d(vol, sigma, stages=2, clip=None, **kw):
     return out
 
 
-def bm4d_u16(vol, sigma, offset, stages=2, **kw):
+def bm4d_u16(vol, sigma, offset, stages=2, port=False, **kw):
     p = {**DEFAULTS, **kw}
     vol = np.ascontiguousarray(vol, dtype=np.uint16)
     nz, ny, nx = vol.shape
     out = np.empty_like(vol)
-    lib().orc_bm4d_u16(_p(vol, ctypes.c_uint16), _p(out, ctypes.c_uint16), nz, ny, nx,
+    (lib().cpu_bm4d_u16 if port else lib().orc_bm4d_u16)(_p(vol, ctypes.c_uint16), _p(out, ctypes.c_uint16), nz, ny, nx,
                        float(sigma), float(offset), float(p["lambda_ht"]), float(p["c_match_ht"]),
                        float(p["c_match_wie"]), float(p["kaiser_beta"]), int(stages))
     return out

@@ -1,5 +1,7 @@
 """Self-consistency of the BM4D oracle (the reference holds no test for its third-party bm4d
 wheel -- parity unpinned -- so these are the properties SURVEY.md section 8c asks for).  CPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -149,3 +151,39 @@ def test_aggregation_denominator_is_a_convolution(oracle):
             acc[tuple(sl_dst)] += k32[t] * out[tuple(sl_src)]
         out = acc
     np.testing.assert_allclose(out, den, rtol=2e-5, atol=1e-12)
+
+
+def test_cpu_port_equals_the_oracle(oracle):
+    """oracle/exabm4d_cpu_port.c (bench.py's cpu_baseline: shared cell sums, SIMD over dx and over
+    transform lines, coloured parallel scatter) against the checker: match tables and 4-D
+    transforms bit-identical, stage sums to fp32 summation order, uint16 results within one count --
+    on aligned and ragged extents, one thread and several."""
+    rng = np.random.default_rng(7)
+    for K in (1, 2, 4, 8, 16):
+        g = rng.normal(0, 300, (K, 8, 8, 8)).astype(np.float32)
+        spec = oracle.group_transform(g)
+        np.testing.assert_array_equal(oracle.group_transform(g, port=True), spec)
+        np.testing.assert_array_equal(oracle.group_transform(spec, inverse=True, port=True),
+                                      oracle.group_transform(spec, inverse=True))
+    for shape, threads in (((24, 28, 32), 3), ((26, 31, 21), 1), ((33, 24, 40), 4)):
+        oracle.set_threads(threads)
+        vol, _ = synth_volume(shape, seed=sum(shape))
+        for c_match in (3.0, 0.6):
+            keys = oracle.blockmatch(vol, 24.0, c_match)
+            np.testing.assert_array_equal(oracle.blockmatch(vol, 24.0, c_match, port=True), keys)
+        keys = oracle.blockmatch(vol, 24.0)
+        num, den = oracle.stage(vol, keys, 24.0)
+        pn, pd = oracle.stage(vol, keys, 24.0, port=True)
+        np.testing.assert_allclose(pn, num, rtol=2e-5, atol=1e-6 * float(np.abs(num).max()))
+        np.testing.assert_allclose(pd, den, rtol=2e-5)
+        basic = oracle.normalize(num, den)
+        wn, wd = oracle.stage(vol, keys, 24.0, basic=basic)
+        qn, qd = oracle.stage(vol, keys, 24.0, basic=basic, port=True)
+        np.testing.assert_allclose(qn, wn, rtol=2e-5, atol=1e-6 * float(np.abs(wn).max()))
+        np.testing.assert_allclose(qd, wd, rtol=2e-5)
+    oracle.set_threads(len(os.sched_getaffinity(0)))
+    u16, _ = synth_volume((40, 36, 44), seed=3, as_u16=True)
+    a = oracle.bm4d_u16(u16, 24.0, 37.0)
+    b = oracle.bm4d_u16(u16, 24.0, 37.0, port=True)
+    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-3

@@ -1,12 +1,15 @@
-set -e
+# gpurun --timeout 1200 -- bash tools/dbg/profile_round.sh : the passes behind profiles/rNN/
+# (reduce afterwards with: python tools/profile_summary.py gpurun_out/prof_round profiles/rNN 1024)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_round; rm -rf $O; mkdir -p $O
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; tail -1 $O/gpu_tests.log
-timeout -k 10 300 python tools/stress_stage.py 384 > $O/stress.log 2>&1; tail -1 $O/stress.log
-timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
-rocprofv3 --kernel-trace --stats -d $O/trace -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 > $O/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/fetch -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/write -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/write.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d $O/sq1 -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/sq1.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $O/sq2 -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 > $O/sq2.log 2>&1
+B="python bench.py --steps 1 --warmup 0 --cpu-sample 0 --bm4dnet 0"
+timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
+rocprofv3 --kernel-trace --stats -d $O/trace -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --bm4dnet 0 > $O/trace.log 2>&1 && echo trace ok
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch -- $B > $O/fetch.log 2>&1 && echo fetch ok
+rocprofv3 --pmc WRITE_SIZE -d $O/write -- $B > $O/write.log 2>&1 && echo write ok
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq1 -- $B > $O/sq1.log 2>&1 && echo sq1 ok
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d $O/sq2 -- $B > $O/sq2.log 2>&1 && echo sq2 ok
+# the raw databases are large: keep the reduced JSON / CSV only
+python tools/profile_summary.py $O $O/summary 1024 > $O/summary.txt 2>&1; tail -12 $O/summary.txt
+find $O -name "*.db" -size +20M -delete
 echo profiling done
