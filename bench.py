@@ -337,6 +337,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
 
+    if args.bm4dnet > 0 and world == 1 and args.mode == "volumes":
+        # the BM4DNet leg needs torch's HIP runtime: load it BEFORE libexabm4d.so pulls in the
+        # system one (two copies of libamdhip64 in one process leave the second without devices)
+        import torch  # noqa: F401
     from aind_exaspim_image_compression import _native
 
     if args.mode == "slabs":

@@ -9,7 +9,4 @@ rocprofv3 --pmc FETCH_SIZE -d $O/fetch -- $B > $O/fetch.log 2>&1 && echo fetch o
 rocprofv3 --pmc WRITE_SIZE -d $O/write -- $B > $O/write.log 2>&1 && echo write ok
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $O/sq1 -- $B > $O/sq1.log 2>&1 && echo sq1 ok
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES -d $O/sq2 -- $B > $O/sq2.log 2>&1 && echo sq2 ok
-# the raw databases are large: keep the reduced JSON / CSV only
-python tools/profile_summary.py $O $O/summary 1024 > $O/summary.txt 2>&1; tail -12 $O/summary.txt
-find $O -name "*.db" -size +20M -delete
-echo profiling done
+du -sh $O; echo profiling done
