@@ -718,8 +718,12 @@ __device__ __forceinline__ void half_shrink_local(f16v (&S)[4], float thr, int& 
         for (int k = 1; k < KH; k++) {
             const bool k0 = fabsf(x[k].x) >= thr, k1 = fabsf(x[k].y) >= thr;
             nnz += (k0 ? 1 : 0) + (k1 ? 1 : 0);
-            A[2 * k] = k0 ? x[k].x : 0.0f;
-            A[2 * k + 1] = k1 ? x[k].y : 0.0f;
+            float f0 = k0 ? x[k].x : 0.0f, f1 = k1 ? x[k].y : 0.0f;
+            // select now: left to itself hipcc keeps the 64-bit compare masks of a whole half group
+            // alive in scalar registers until the inverse transforms and spills 64 of them per group
+            asm volatile("" : "+v"(f0), "+v"(f1));
+            A[2 * k] = f0;
+            A[2 * k + 1] = f1;
         }
         S[jp] = A;
     }
