@@ -295,6 +295,67 @@ def run_slabs(args, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def run_chunks(args, rank, local_rank, world, dist):
+    """BASELINE config 4: N ranks, ONE volume of N*size planes in chunk-local mode -- 256^3 cores
+    with an 8-voxel halo, every padded chunk denoised in isolation.  A rank owns whole layers of
+    chunks; the only exchange is the raw uint16 input halo (8 planes to each slab neighbour, RCCL
+    isend / irecv), overlapped with the chunk layers that do not need it.  Weak scaling."""
+    import torch
+    from aind_exaspim_image_compression.distributed import (ChunkedSlabDenoiser, denoise_chunked_slab,
+                                                            plan_chunk_slabs)
+    n, chunk, halo = args.size, args.chunk, 8
+    shape = (n * world, n, n)
+    plan = plan_chunk_slabs(shape[0], world, rank, chunk=chunk, halo=halo)
+    dev = torch.device("cuda", local_rank)
+    host = synth_u16(shape, seed=3000, z_range=(plan.z0, plan.z1))
+    own = torch.from_numpy(host.view(np.int16)).to(dev)
+    raw = torch.zeros((plan.p1 - plan.p0, n, n), dtype=torch.int16, device=dev)
+    den = ChunkedSlabDenoiser(SIGMA, OFFSET, dev, chunk=chunk, halo=halo)
+
+    def step():
+        raw[plan.core] = own                   # only the owned planes are known before the exchange
+        return denoise_chunked_slab(raw, plan, den.run, chunk=chunk, dist=dist)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        resid = (out[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float() - \
+                (own[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float()
+        print(json.dumps({
+            "metric": "denoised+encoded voxels/s on 1024^3 uint16",
+            "value": world * n ** 3 * args.steps / elapsed,
+            "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{shape[0]}x{n}x{n} uint16 volume, chunk-local two-stage BM4D: "
+                                   f"{chunk}^3 cores + {halo}-voxel halo, {world} z-slab(s) of whole "
+                                   "chunk layers, raw-input halo exchange overlapped with interior layers",
+                       "volume": list(shape), "stages": 2, "encode": "none",
+                       "sharding": "chunk layers per rank, RCCL point-to-point exchange of 8 input planes"},
+            "residual_std": float(resid.std()),
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,11 +363,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="cubic volume edge per GPU")
     ap.add_argument("--stages", type=int, default=2)
-    ap.add_argument("--mode", choices=["volumes", "slabs"], default="volumes",
+    ap.add_argument("--chunk", type=int, default=256, help="core edge of --mode chunks")
+    ap.add_argument("--mode", choices=["volumes", "slabs", "chunks"], default="volumes",
                     help="N>1 sharding: 'volumes' = one independent volume per rank, no "
                          "data-path collective (default); 'slabs' = one (N*size) x size x size "
                          "volume split into z-slabs with an RCCL halo exchange of the basic "
-                         "estimate between the two stages (distributed.py)")
+                         "estimate between the two stages (distributed.py); 'chunks' = BASELINE "
+                         "config 4: the same volume in chunk-local mode (--chunk^3 cores + 8-voxel "
+                         "halo), raw-input halo exchange only")
     ap.add_argument("--no-encode", action="store_true",
                     help="time the denoiser alone (the metric's step includes the encode legs)")
     ap.add_argument("--cpu-sample", type=int, default=1,
@@ -345,6 +409,8 @@ def main():
 
     if args.mode == "slabs":
         return run_slabs(args, rank, local_rank, world, dist)
+    if args.mode == "chunks":
+        return run_chunks(args, rank, local_rank, world, dist)
 
     ctx = _native.context(local_rank)
     shape = (args.size,) * 3
