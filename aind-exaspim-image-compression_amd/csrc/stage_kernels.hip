@@ -662,22 +662,53 @@ __device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLa
 #ifndef EXABM4D_X2INV
 #define EXABM4D_X2INV 1                        // inverse transforms of four blocks as two interleaved pairs
 #endif
-#ifndef EXABM4D_HTY
-#define EXABM4D_HTY 2
+// Per-kernel geometry of the two-waves-per-group kernels.  The hard-threshold kernel needs 133
+// registers and runs THREE waves per SIMD (12 per workgroup, six pairs); the Wiener kernel holds
+// two spectra (245 registers) and stays at two (8 per workgroup).  LDS = ring (NPL planes of
+// ROWS x COLS doubles) + one transpose buffer per wave, at most 160 KB.
+#ifndef EXABM4D_HT_NW
+#define EXABM4D_HT_NW 12
 #endif
-#ifndef EXABM4D_HNPL
-#define EXABM4D_HNPL 22
+#ifndef EXABM4D_HT_TY
+#define EXABM4D_HT_TY 2
 #endif
-constexpr int HTY = EXABM4D_HTY;               // grid points per tile in y (x keeps TILE_R = 4)
-constexpr int HROWS = (HTY - 1) * STEP + 18;  // region rows: 22 (26 for 3 points)
-constexpr int HPS = ((HROWS * REG + 23) / 32) * 32 + 8;   // plane stride in elements, 8 (mod 32): 680 (808)
-constexpr int HNPL = EXABM4D_HNPL;            // ring planes: 18 + 4 per layer a wave may run ahead of the flush
-constexpr int HGATE = (HNPL - 18) / STEP;     // extra layers of planes: a layer waits for the flush
-                                              // of layer - 1 - HGATE
+#ifndef EXABM4D_HT_TX
+#define EXABM4D_HT_TX 4
+#endif
+#ifndef EXABM4D_HT_NPL
+#define EXABM4D_HT_NPL 18
+#endif
+#ifndef EXABM4D_WIE_NW
+#define EXABM4D_WIE_NW 8
+#endif
+#ifndef EXABM4D_WIE_TY
+#define EXABM4D_WIE_TY 2
+#endif
+#ifndef EXABM4D_WIE_TX
+#define EXABM4D_WIE_TX 4
+#endif
+#ifndef EXABM4D_WIE_NPL
+#define EXABM4D_WIE_NPL 22
+#endif
+template <int NW_, int TY_, int TX_, int NPL_>
+struct HalfGeom {
+    static constexpr int NW = NW_;                      // waves: pair p = wave >> 1, half h = wave & 1 (the
+                                                        // waves of a pair sit on different SIMDs)
+    static constexpr int TY = TY_, TX = TX_;            // grid points per tile in y and x
+    static constexpr int ROWS = (TY - 1) * STEP + 18;   // region rows / columns: 4 per further grid point
+    static constexpr int COLS = (TX - 1) * STEP + 18;   //   + 8 (block) + 2 * 5 (search)
+    static constexpr int PS = ((ROWS * COLS + 23) / 32) * 32 + 8;  // plane stride in elements, 8 (mod 32)
+    static constexpr int NPL = NPL_;                    // ring planes: 18 live ones + slack for running
+                                                        // ahead of the flush (per-block gate below)
+    static constexpr size_t LDS_FLOATS = (size_t)2 * NPL * PS + (size_t)NW * 2 * TBUF + 4 + 2 * NW + 8;
+    static_assert(NW % 2 == 0 && NW <= 16 && NPL >= 18 && NPL <= 26, "pairs of waves; at most 3 layers in flight");
+    static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "ring + transpose buffers exceed the CU's LDS");
+};
+template <bool WIENER>
+struct HalfCfg : HalfGeom<EXABM4D_HT_NW, EXABM4D_HT_TY, EXABM4D_HT_TX, EXABM4D_HT_NPL> {};
+template <>
+struct HalfCfg<true> : HalfGeom<EXABM4D_WIE_NW, EXABM4D_WIE_TY, EXABM4D_WIE_TX, EXABM4D_WIE_NPL> {};
 constexpr int HNCNT = 8;                      // per-layer report counters
-constexpr int HNW = 8;                        // waves: pair p = wave >> 1, half h = wave & 1 (the waves
-                                              // of a pair sit on different SIMDs; the two waves of
-                                              // a SIMD belong to different pairs and drift apart)
 typedef double ring_t;                        // LDS fp64 atomic add is native on gfx950 (8 cycles per
                                               // wave-instruction; ds_add_f32 takes 192): lock-free ring
 
@@ -750,10 +781,12 @@ __device__ __forceinline__ void half_unshrink_local(f16v (&S)[4], const f2 (&app
 
 // Numerator ring of the two-waves-per-group kernels: move plane z to global memory (float atomics:
 // neighbouring tiles overlap) and zero it.  One wave.
+template <class C>
 __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict__ num, int z,
                                                 const TileGeom& tg, const VolGeom& g, int lane) {
-    ring_t* plane = ring + ((z + 5) % HNPL) * HPS;
-    constexpr int N = HROWS * REG, U = 4;     // four LDS reads in flight per lane
+    constexpr int REG = C::COLS;
+    ring_t* plane = ring + ((z + 5) % C::NPL) * C::PS;
+    constexpr int N = C::ROWS * REG, U = 4;   // four LDS reads in flight per lane
     for (int rem0 = lane; rem0 < N; rem0 += 64 * U) {
         ring_t v[U];
 #pragma unroll
@@ -823,12 +856,14 @@ __device__ __forceinline__ bool process_half_group(
     int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
     const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, ring_t* ring,
     float* __restrict__ cvol, f2* tb,
-    f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int layer, int target, int lane,
-    long long g_nvox
+    f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int& seen, int layer, int target,
+    int lane, long long g_nvox
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
 #endif
     ) {
+    using C = HalfCfg<WIENER>;
+    constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, REG = C::COLS;
     constexpr int NP = WIENER ? 8 : 4;         // f2 values per lane swapped with the partner
     const int hi = lane >> 3, lo = lane & 7;
     STAMP(t0);
@@ -1084,13 +1119,27 @@ __device__ __forceinline__ bool process_half_group(
         STAMP(t2);
         STAMP_ADD(1, t1, t2);
         if (K > 1) wait_flag(sync + HNW + partner, seq, lane);
-        // Ring slots are re-used every HNPL planes: the planes this layer adds on top alias the ones
-        // layer - 1 - HGATE retired, so lock[1] (layers retired so far, in order) must be >= layer - HGATE.
-        if (lane == 0) {
-            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   layer - HGATE)
-                __builtin_amdgcn_s_sleep(8);
-        }
+        // Ring slots are re-used every HNPL planes.  A block whose top plane is z0 + t (t = dz + 7)
+        // lands on the slot of plane z0 + t - HNPL, which left the ring when the layer
+        // ceil((HNPL - 5 - t) / 4) layers back was closed: the block may be added once lock[1]
+        // (layers retired so far, in order) has reached layer + 1 - that number.  The gate is per
+        // block, right in front of its adds -- only the blocks that reach highest wait for the
+        // latest flush -- and the last value seen of the monotonic counter is kept, so most
+        // blocks cost no LDS read at all.
+        auto gate = [&](int k) {
+            const int t = __builtin_amdgcn_readlane(my_dz, k) + 7;
+            const int need = layer + 1 - (HNPL - 5 - t + 3) / 4;
+            if (seen < need) {
+                cbar();
+                int v = 0;
+                if (lane == 0) {
+                    while ((v = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+                        __builtin_amdgcn_s_sleep(8);
+                }
+                seen = __builtin_amdgcn_readfirstlane(v);
+                cbar();
+            }
+        };
         STAMP(t3);
         STAMP_ADD(5, t2, t3);
         // ring offsets of a block: first plane slot of the lane's z, (y, x) offset of the lane's x
@@ -1117,9 +1166,13 @@ __device__ __forceinline__ bool process_half_group(
                 }
                 pair_inv_x2(T, tb, hi, lo, v2, w2);
                 STAMP(tl1);
+                gate(kb + kl);
                 ring_add(ring_off(kb + kl), v2, 0);
+                gate(kb + kl + 1);
                 ring_add(ring_off(kb + kl + 1), v2, 1);
+                gate(kb + kl + 2);
                 ring_add(ring_off(kb + kl + 2), w2, 0);
+                gate(kb + kl + 3);
                 ring_add(ring_off(kb + kl + 3), w2, 1);
                 STAMP(tl2);
                 STAMP_ADD(4, tl1, tl2);
@@ -1134,8 +1187,12 @@ __device__ __forceinline__ bool process_half_group(
                     v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
                 pair_inv(T, tb, hi, lo, v2);
                 STAMP(tl1);
+                gate(kb + kl);
                 ring_add(ring_off(kb + kl), v2, 0);
-                if constexpr (two) ring_add(ring_off(kb + kl2), v2, 1);
+                if constexpr (two) {
+                    gate(kb + kl2);
+                    ring_add(ring_off(kb + kl2), v2, 1);
+                }
                 STAMP(tl2);
                 STAMP_ADD(4, tl1, tl2);
             }
@@ -1154,8 +1211,7 @@ __device__ __forceinline__ bool process_half_group(
         // whose planes this layer re-uses have been retired: at most 2 + HGATE layers are in flight,
         // the report counters have eight slots.
         if (lane == 0) {
-            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   layer - HGATE)
+            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < layer - 2)
                 __builtin_amdgcn_s_sleep(8);
         }
         cbar();
@@ -1175,11 +1231,13 @@ typedef DctTable HalfTable;
 typedef Dct7 HalfTable;       // seven scalars instead of a 64-entry table in SGPRs (dct_pairs.h)
 #endif
 template <bool WIENER>
-__global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
+__global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
     const uint32_t* __restrict__ keys_all, VolGeom g, HalfTable T, const float* __restrict__ win_g,
     float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x,
     int layers_per_chunk) {
+    using C = HalfCfg<WIENER>;
+    constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, HTY = C::TY, HTX = C::TX;
     extern __shared__ __align__(16) float lds[];
     ring_t* ring = reinterpret_cast<ring_t*>(lds);         // [HNPL][HPS] numerator sums (fp64)
     // readfirstlane: the wave index steers register indexing below and must be provably uniform
@@ -1200,10 +1258,10 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int iy0 = HTY * ty, ix0 = TILE_R * tx;
+    const int iy0 = HTY * ty, ix0 = HTX * tx;
     TileGeom tg;
     tg.nry = min(HTY, g.gy - iy0);
-    tg.nrx = min(TILE_R, g.gx - ix0);
+    tg.nrx = min(HTX, g.gx - ix0);
     tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
     tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
     const int nrefs = tg.nry * tg.nrx;
@@ -1225,6 +1283,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 
     const int pairid = wave >> 1;
     int seq = 0;
+    int seen = 0;           // last value read of lock[1] (layers retired), see the per-block gate
     // 8-point transforms on the matrix pipe (dct_pairs.h) where the registers allow it
 #if EXABM4D_MFMA_DCT
     constexpr bool ON_MFMA = WIENER ? (EXABM4D_MFMA_DCT >= 2) : (EXABM4D_MFMA_DCT >= 1);
@@ -1240,7 +1299,9 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     for (int iz = izb; iz < ize; iz++) {
         const int layer = iz - izb;
         const int z0 = grid_pos(iz, g.az, g.nz);
-        for (int r = pairid; r < nrefs; r += HNW / 2) {
+        // the tile's groups go round the pairs, starting one pair further every layer: when the
+        // groups do not divide by the pairs the extra ones rotate
+        for (int r = (pairid + layer) % (HNW / 2); r < nrefs; r += HNW / 2) {
             const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
             const int iy = iy0 + jy, ix = ix0 + jx;
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
@@ -1262,7 +1323,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
 #endif
             const bool closer = process_half_group<WIENER>(
                 noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, ring, cvol, tb,
-                partner_tb, lock, sync, cnt, wave, seq, layer, 2 * nrefs, lane, g.nvox
+                partner_tb, lock, sync, cnt, wave, seq, seen, layer, 2 * nrefs, lane, g.nvox
 #ifdef EXABM4D_STAMPS
                 , st
 #endif
@@ -1274,7 +1335,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (iz + 1 < ize) {
                     const int zn = grid_pos(iz + 1, g.az, g.nz);
-                    for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane(ring, num, z, tg, g, lane);
+                    for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane<C>(ring, num, z, tg, g, lane);
                 }
                 cbar();
                 // layers retire in order: wait for the previous layer's flush, then count this one
@@ -1292,7 +1353,7 @@ __global__ __launch_bounds__(HNW * 64) void stage_half_kernel(
     __syncthreads();
     if (ize > izb) {
         const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
-        for (int z = base + wave; z < base + HNPL; z += HNW) flush_num_plane(ring, num, z, tg, g, lane);
+        for (int z = base + wave; z < base + HNPL; z += HNW) flush_num_plane<C>(ring, num, z, tg, g, lane);
     }
 #ifdef EXABM4D_STAMPS
     st[7] = stamp() - tk0;
@@ -1327,43 +1388,39 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         const size_t n = (size_t)g.nvox * (size_t)batch;
         hipError_t e = hipMemsetAsync(cwork, 0, n * sizeof(float), stream);
         if (e != hipSuccess) return e;
-        const int hty = (g.gy + HTY - 1) / HTY;
-        const long long htiles = (long long)hty * tiles_x * batch;
-        // z chunks: at least ~4 work items per CU, and -- while a chunk keeps >= 16 layers, so that
-        // its ring start-up and final flush stay small -- about 128 per CU: a 1024^3 volume has
-        // only 21 tile columns per CU and the last ones leave most of the chip idle (measured at
-        // 1024^3: 1 chunk 242 / 352 ms, 8 chunks 237 / 339 ms, 32 chunks 245 / 345 ms; 512^3:
-        // 1 chunk 33.7 / 48.3 ms, 7 chunks 30.9 / 43.7 ms).
-        int hchunks = (int)((1024 + htiles - 1) / htiles);
-        const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
-        if (hchunks < fine) hchunks = fine;
-        if (g_stage_chunks > 0) hchunks = g_stage_chunks;
-        if (hchunks < 1) hchunks = 1;
-        if (hchunks > g.gz) hchunks = g.gz;
-        const int hlpc = (g.gz + hchunks - 1) / hchunks;
-        hchunks = (g.gz + hlpc - 1) / hlpc;
-        const dim3 hgrid((unsigned)(hty * tiles_x), (unsigned)hchunks, (unsigned)batch);
-        const size_t lds = sizeof(float) * (2 * HNPL * HPS + HNW * 2 * TBUF + 4 + 2 * HNW + HNCNT);
 #if EXABM4D_MFMA_DCT
         const DctTable& HT = T;
 #else
         Dct7 HT;
         if (!make_dct7(T, HT)) return hipErrorInvalidValue;    // the table lost its symmetry
 #endif
-        if (basic) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(stage_half_kernel<true>, hgrid, dim3(HNW * 64), lds, stream, noisy, basic,
-                               keys, g, HT, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
-        } else {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(stage_half_kernel<false>, hgrid, dim3(HNW * 64), lds, stream, noisy,
-                               basic, keys, g, HT, win_dev, thr, sigma2, num, cwork, tiles_x, hlpc);
-        }
-        e = hipGetLastError();
+        auto launch = [&](auto wiener_c) -> hipError_t {
+            constexpr bool W = decltype(wiener_c)::value;
+            using C = HalfCfg<W>;
+            const int hty = (g.gy + C::TY - 1) / C::TY, htx = (g.gx + C::TX - 1) / C::TX;
+            const long long htiles = (long long)hty * htx * batch;
+            // z chunks: at least ~4 work items per CU, and -- while a chunk keeps >= 16 layers, so
+            // that its ring start-up and final flush stay small -- about 128 per CU (a 1024^3
+            // volume has few tile columns per CU and the last ones leave most of the chip idle;
+            // measured flat between 2 and 8 chunks at 1024^3).
+            int hchunks = (int)((1024 + htiles - 1) / htiles);
+            const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
+            if (hchunks < fine) hchunks = fine;
+            if (g_stage_chunks > 0) hchunks = g_stage_chunks;
+            if (hchunks < 1) hchunks = 1;
+            if (hchunks > g.gz) hchunks = g.gz;
+            const int hlpc = (g.gz + hchunks - 1) / hchunks;
+            hchunks = (g.gz + hlpc - 1) / hlpc;
+            const dim3 hgrid((unsigned)(hty * htx), (unsigned)hchunks, (unsigned)batch);
+            const size_t lds = sizeof(float) * C::LDS_FLOATS;
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<W>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return err;
+            hipLaunchKernelGGL(stage_half_kernel<W>, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys,
+                               g, HT, win_dev, thr, sigma2, num, cwork, htx, hlpc);
+            return hipGetLastError();
+        };
+        e = basic ? launch(std::true_type{}) : launch(std::false_type{});
         if (e != hipSuccess) return e;
         return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d,
                                        den_overwrite, stream);
