@@ -1299,9 +1299,13 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     for (int iz = izb; iz < ize; iz++) {
         const int layer = iz - izb;
         const int z0 = grid_pos(iz, g.az, g.nz);
-        // the tile's groups go round the pairs, starting one pair further every layer: when the
-        // groups do not divide by the pairs the extra ones rotate
-        for (int r = (pairid + layer) % (HNW / 2); r < nrefs; r += HNW / 2) {
+        // The tile's groups go round the pairs, starting one pair further every layer, so that the
+        // extra groups rotate when they do not divide by the pairs -- but only while every pair has
+        // a group in every layer: a pair without one would skip ahead, a layer could then be
+        // complete before the one below it, and the ring protocol counts on layers completing in
+        // order (edge tiles with fewer groups than pairs keep the fixed assignment).
+        const int rot = nrefs >= HNW / 2 ? layer % (HNW / 2) : 0;
+        for (int r = (pairid + rot) % (HNW / 2); r < nrefs; r += HNW / 2) {
             const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
             const int iy = iy0 + jy, ix = ix0 + jx;
             const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
@@ -1333,19 +1337,21 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
                 if (lane == 0)
                     __hip_atomic_store(cnt + (layer & (HNCNT - 1)), 0, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                // layers retire in order: the layers below are complete (and flushed) before this
+                // one's planes leave the ring
+                if (lane == 0) {
+                    while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP) != layer)
+                        __builtin_amdgcn_s_sleep(2);
+                }
+                cbar();
                 if (iz + 1 < ize) {
                     const int zn = grid_pos(iz + 1, g.az, g.nz);
                     for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane<C>(ring, num, z, tg, g, lane);
                 }
                 cbar();
-                // layers retire in order: wait for the previous layer's flush, then count this one
-                if (lane == 0) {
-                    while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP) != layer)
-                        __builtin_amdgcn_s_sleep(2);
-                    __hip_atomic_store(lock + 1, layer + 1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if (lane == 0)
+                    __hip_atomic_store(lock + 1, layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 cbar();
             }
         }

@@ -155,6 +155,37 @@ def test_half_group_kernel_equals_single_wave_kernel(ctx, oracle):
     _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
 
 
+def test_tall_ragged_volume_pairs_equal_single_wave_kernels(ctx):
+    """Regression (round 2): tile columns that march over MANY layers in one z chunk, with edge
+    tiles that hold fewer groups than the workgroup has wave pairs -- a pair without a group in a
+    layer must not let a layer complete (and its ring planes be flushed) before the layer below.
+    The two-waves-per-group kernels against the one-wave-per-group kernels (one stage: same match
+    tables, only the order of the aggregation sums differs -> at most one count)."""
+    import bench
+    shape = (253, 61, 57)
+    vol = bench.synth_u16(shape, 7)
+    vol[:40] = 0                                  # zero padding: every candidate matches
+    vol[:, :, -9:] = 0
+    d_in = ctx.to_device(vol)
+    d_out = ctx.alloc(vol.nbytes)
+    outs = []
+    ctx.set_option("stage_chunks", 1)             # one chunk: 63 layers per tile column
+    try:
+        for pairs in (1, 0, 1):
+            ctx.set_option("stage_pairs", pairs)
+            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0, stages=1)
+            ctx.sync()
+            outs.append(d_out.download(shape, np.uint16).astype(np.int32))
+    finally:
+        ctx.set_option("stage_pairs", 1)
+        ctx.set_option("stage_chunks", 0)
+        d_in.free()
+        d_out.free()
+    for a in (outs[0], outs[2]):
+        d = np.abs(a - outs[1])
+        assert d.max() <= 1 and np.mean(d > 0) < 5e-3, (int(d.max()), int((d > 1).sum()))
+
+
 def test_wiener_stage(ctx, oracle):
     shape = (40, 44, 48)
     noisy, _ = synth_volume(shape, seed=13)
