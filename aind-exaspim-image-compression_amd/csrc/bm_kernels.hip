@@ -96,6 +96,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     uint32_t list[MAXG];
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
+    uint32_t thr = keymax;       // min(list[15], keymax): a key below it enters the list
     // bit d set iff candidate displacement dx = d - 5 keeps the block inside the volume
     uint32_t xmask = 0;
 #pragma unroll
@@ -278,12 +279,23 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                             for (int d = 0; d < SWIN; d++) {
                                 const float* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
                                 const float* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
-                                const float S = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]);
+                                // S = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]) as three plain adds: left
+                                // to the SLP vectoriser this becomes two packed adds, three moves and
+                                // two wait states
+                                float s0 = c0[0] + c0[TCX];
+                                asm("" : "+v"(s0));        // (an opaque use keeps the two sums apart)
+                                const float s1 = c1[0] + c1[TCX];
+                                const float S = s0 + s1;
                                 const uint32_t code = (d == RAD && self_row) ? 0u : cbase + d;
                                 const bool valid = vzy && ((xmask >> d) & 1u);
                                 uint32_t key = (__float_as_uint(S) & KEY_DMASK) | code;
-                                key = (valid && key < keymax) ? key : KEY_EMPTY;
-                                if (__any(key < list[MAXG - 1])) list_insert(list, key);
+                                key = valid ? key : KEY_EMPTY;
+                                // thr = min(16th best so far, admission bound): one compare decides
+                                if (__any(key < thr)) {
+                                    const uint32_t kins = key < thr ? key : KEY_EMPTY;
+                                    list_insert_inplace(list, kins);
+                                    thr = min(list[MAXG - 1], keymax);
+                                }
                             }
                         }
                     }

@@ -64,6 +64,17 @@ __device__ __forceinline__ void list_insert(uint32_t (&list)[MAXG], uint32_t key
     list[0] = min(list[0], key);
 }
 
+// The same update strictly in place, top entry first (every v_med3 reads the OLD lower neighbour,
+// which has not been rewritten yet).  Written as instructions because hipcc, given the C form
+// behind a wave-uniform branch, builds the new list in sixteen other registers and copies it back
+// with eight 64-bit moves.
+__device__ __forceinline__ void list_insert_inplace(uint32_t (&list)[MAXG], uint32_t key) {
+#pragma unroll
+    for (int k = MAXG - 1; k >= 1; k--)
+        asm volatile("v_med3_u32 %0, %1, %2, %0" : "+v"(list[k]) : "v"(list[k - 1]), "v"(key));
+    asm volatile("v_min_u32 %0, %0, %1" : "+v"(list[0]) : "v"(key));
+}
+
 // Workgroups of a launch are dealt round-robin to the 8 XCDs, each with its own L2.  Remapping
 // the linear workgroup id so that every XCD walks one contiguous range of tiles keeps the halo
 // data neighbouring tiles share in the same L2 instead of fetching it once per XCD.
