@@ -96,6 +96,7 @@ SIGNATURES = {
     "exabm4d_tables": (_I, [_PP, c_f32p, c_f32p]),
     "exabm4d_scratch_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "exabm4d_blockmatch_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _F, _F, _PP, c_vp]),
+    "exabm4d_blockmatch_u16_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _F, _F, _PP, c_vp]),
     "exabm4d_match_decode": (_I, [c_u32p, _I, _I, _I, _I, _I, c_i64p, c_f32p,
                                   ctypes.POINTER(_I)]),
     "exabm4d_stage_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, c_vp, c_vp]),
@@ -305,6 +306,13 @@ class Context:
         self._check(lib().exabm4d_blockmatch_dev(self.handle, _ptr(vol), nz, ny, nx, batch,
                                                  float(sigma), float(c_match), ctypes.byref(p),
                                                  _ptr(keys)))
+
+    def blockmatch_u16(self, vol, shape, sigma, c_match, keys, params=None, batch=1):
+        p = params or default_params()
+        nz, ny, nx = shape
+        self._check(lib().exabm4d_blockmatch_u16_dev(self.handle, _ptr(vol), nz, ny, nx, batch,
+                                                     float(sigma), float(c_match), ctypes.byref(p),
+                                                     _ptr(keys)))
 
     def stage(self, noisy, basic, keys, shape, sigma, num, den, params=None, batch=1):
         p = params or default_params()

@@ -323,6 +323,241 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Integer tile kernel for uint16 volumes (stage-1 matching of the uint16 pipelines).
+//
+// The noisy volume of the uint16 entry points is `(float)v - offset`: differences of two voxels are
+// exact integers, so every partial sum of the specification's fmaf chains is an integer, and as
+// long as a block distance stays below 2^24 it is EXACT in fp32 -- the chain order no longer
+// matters and the same number can be formed in integer arithmetic.  A candidate is admitted only
+// below keymax <= 2^24 (checked by the launcher: c_match * sigma^2 * 512 < 2^24), so for every
+// candidate that can enter a match table the integer sum converted to float has exactly the bits
+// the float kernel produces, and everything else is rejected by both.  The integer form costs
+// half the vector-ALU cycles: v_pk_sub_i16 (saturating) forms two differences, v_dot2_i32_i16
+// (saturating) squares and accumulates both -- two 2-cycle instructions per two (voxel,
+// displacement) pairs against two 4-cycle packed-fp32 ones -- and a staged plane is half the bytes.
+//
+// Input: the volume with every voxel XOR 0x8000 (= v - 32768 as int16), in the library's scratch
+// with mapped memory around it (written next to the fp32 counts by the uint16 pipelines).  The
+// bias makes the saturating int16 subtraction exact for |a - w| < 32768; a saturated difference
+// squares to > 2^29 and can never be admitted.  nx must be even (4-byte aligned LDS-DMA rows).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+template <int TCY_, int TCX_>
+struct TileShape16 {
+    static constexpr int TCY = TCY_, TCX = TCX_;
+    static constexpr int TRY = TCY - 1, TRX = TCX - 1;
+    static constexpr int PROWS = 4 * (TCY - 1) + 3 + NE;          // staged rows (37 / 21)
+    static constexpr int PCOLS = ((4 * TCX + 10 + 7) / 8) * 8;    // staged uint16 columns (48 / 80)
+    // row stride in uint16: two cell rows of a 32-lane ds_read_b64 group must fall into different
+    // 16-bank windows (8 x 8: 56 = 24 mod 32), one 16-lane cell row is 32 banks (4 x 16: 80 = 16 mod 32)
+    static constexpr int PSTR = TCX == 8 ? 56 : 80;
+    static constexpr int PCH = PSTR / 8;                          // 16-byte chunks per staged row
+    static constexpr int NDMA = (PROWS * PCH + 63) / 64;
+    static constexpr int PLANE_DW = NDMA * 256;                   // dwords of one plane buffer
+    static constexpr int XCH_DW = (NE / 2) * SWIN * 64;           // cell-sum exchange: 33 sums x 64 cells
+    static constexpr int PBUF = PLANE_DW > XCH_DW ? PLANE_DW : XCH_DW;
+    static_assert(TCY * TCX == 64 && PCOLS <= PSTR, "one wave per cell layer");
+};
+
+template <class TS>
+__global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restrict__ vol_all, VolGeom g,
+                                                        uint32_t keymax,
+                                                        uint32_t* __restrict__ keys_all, int tiles_y,
+                                                        int tiles_x) {
+    constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS, PCOLS = TS::PCOLS,
+                  PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
+    __shared__ __align__(16) uint32_t pbuf_all[TCZ][2][PBUF];
+
+    const uint16_t* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
+    uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
+
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int cx = lane % TCX, cy = lane / TCX, cz = tid >> 6;
+    const int ix = TRX * tx + cx, iy = TRY * ty + cy, iz = TRZ * tz + cz;
+    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
+
+    const int qz = min(STEP * iz, g.nz - STEP), qy = min(STEP * iy, g.ny - STEP),
+              qx = min(STEP * ix, g.nx - STEP);
+    // staged window: rows Y0 + dylo ..., columns X0 ... with X0 even (one column more to the left
+    // than the search needs): cell cx finds candidate column x + d of its voxel x at staged
+    // column 4 cx + 1 + x + d
+    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD - 1, Z0 = STEP * (TRZ * tz + cz);
+
+    const bool ref_ok = cx < TRX && cy < TRY && cz < TRZ && iz < g.az && iy < g.ay && ix < g.ax;
+    const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
+
+    uint32_t list[MAXG];
+#pragma unroll
+    for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
+    uint32_t thr = keymax;
+    uint32_t xmask = 0;
+#pragma unroll
+    for (int d = 0; d < SWIN; d++)
+        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
+
+    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
+    auto issue_dma = [&](int step, uint32_t* dst) {
+        const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
+        const int dylo = pass == 0 ? -RAD : 1;
+        const int pz = min(max(Z0 + z + dz, 0), g.nz - 1);
+        const uint16_t* plane = vol + (size_t)pz * sz;
+        int l = lane;
+        asm volatile("" : "+v"(l));
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) {
+            const unsigned p = 64u * i + (unsigned)l;
+            const unsigned r0 = (p * (65536u / PCH + 1u)) >> 16;          // p / PCH for p < 2^12
+            const unsigned r = min(r0, (unsigned)(PROWS - 1));
+            const unsigned q = min(p - r0 * PCH, (unsigned)(PCOLS / 8 - 1));
+            const int yy = yin ? Y0 + dylo + (int)r : min(max(Y0 + dylo + (int)r, 0), g.ny - 1);
+            const uint16_t* src = plane + (ptrdiff_t)yy * (ptrdiff_t)sy + (X0 + 8 * (int)q);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
+        }
+    };
+
+    if (TRZ * tz + cz > g.az) {
+        for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
+        return;
+    }
+    issue_dma(0, pbuf_all[cz][0]);
+
+    int acc[NE][SWIN];
+#pragma unroll
+    for (int e = 0; e < NE; e++)
+#pragma unroll
+        for (int d = 0; d < SWIN; d++) acc[e][d] = 0;
+
+#pragma unroll 1
+    for (int step = 0; step < NSTEP; step++) {
+        const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
+        const int dylo = pass == 0 ? -RAD : 1;
+        uint32_t* cur = pbuf_all[cz][step & 1];
+        uint32_t* nxt = pbuf_all[cz][(step + 1) & 1];
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // own cell plane z: four rows of four biased uint16 (two dwords each)
+        uint2 A[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint32_t* ap = reinterpret_cast<const uint32_t*>(
+                vol + (size_t)(qz + z) * sz + (size_t)(qy + y) * sy + qx);
+            A[y] = make_uint2(ap[0], ap[1]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (step + 1 < NSTEP) issue_dma(step + 1, nxt);
+
+        {
+            const uint32_t* wrow = cur + ((4 * cy) * PSTR + 4 * cx) / 2;       // dword index
+            uint2 wq[4], wn[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) wq[j] = *reinterpret_cast<const uint2*>(wrow + 2 * j);
+#pragma unroll
+            for (int rp = 0; rp < 3 + NE; rp++) {
+                if (rp + 1 < 3 + NE) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        wn[j] = *reinterpret_cast<const uint2*>(wrow + (rp + 1) * (PSTR / 2) + 2 * j);
+                }
+                asm volatile("" ::: "memory");
+                // W[i] = staged columns (2 i, 2 i + 1); Wo[i] = columns (2 i + 1, 2 i + 2)
+                const uint32_t W[8] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
+                uint32_t Wo[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) Wo[i] = __builtin_amdgcn_alignbit(W[i + 1], W[i], 16);
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    const int e = rp - y;
+                    if (e >= 0 && e < NE) {
+#pragma unroll
+                        for (int xp = 0; xp < 2; xp++) {
+                            const s16x2 a = __builtin_bit_cast(s16x2, xp ? A[y].y : A[y].x);
+#pragma unroll
+                            for (int d = 0; d < SWIN; d++) {
+                                const int j = 1 + 2 * xp + d;            // staged column of voxel x = 2 xp
+                                const uint32_t wp = (j & 1) ? Wo[(j - 1) / 2] : W[j / 2];
+                                const s16x2 t = __builtin_elementwise_sub_sat(a, __builtin_bit_cast(s16x2, wp));
+                                acc[e][d] = __builtin_amdgcn_sdot2(t, t, acc[e][d], true);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) wq[j] = wn[j];
+            }
+        }
+        asm volatile("" ::: "memory");
+
+        if (z == 3) {
+            const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
+            uint32_t* mine = cur + lane;
+            const uint32_t* lo_w = cur + lane;
+            const uint32_t* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;
+#pragma unroll
+            for (int e0 = 0; e0 < NE; e0 += NE / 2) {
+#pragma unroll
+                for (int e = e0; e < e0 + NE / 2; e++)
+#pragma unroll
+                    for (int d = 0; d < SWIN; d++) {
+                        // cell sums are capped at 2^27 so that eight of them cannot wrap; a capped
+                        // sum is far beyond any admissible distance
+                        const uint32_t c = min((uint32_t)acc[e][d], 1u << 27);
+                        const uint32_t right = (uint32_t)__builtin_amdgcn_update_dpp(
+                            0, (int)c, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
+                        mine[64 * ((e - e0) * SWIN + d)] = c + right;
+                    }
+                __syncthreads();
+                if (ref_ok) {
+#pragma unroll
+                    for (int e = e0; e < e0 + NE / 2; e++) {
+                        const int dy = dylo + e;
+                        if (dy <= RAD) {
+                            const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
+                            const uint32_t cbase =
+                                1u + (uint32_t)(((dz + RAD) * SWIN + (dy + RAD)) * SWIN);
+                            const bool self_row = (dz == 0) && (dy == 0);
+#pragma unroll
+                            for (int d = 0; d < SWIN; d++) {
+                                const uint32_t* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
+                                const uint32_t* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
+                                const uint32_t S = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]);
+                                const uint32_t code = (d == RAD && self_row) ? 0u : cbase + d;
+                                const bool valid = vzy && ((xmask >> d) & 1u);
+                                uint32_t key = (__float_as_uint((float)S) & KEY_DMASK) | code;
+                                key = valid ? key : KEY_EMPTY;
+                                if (__any(key < thr)) {
+                                    const uint32_t kins = key < thr ? key : KEY_EMPTY;
+                                    list_insert_inplace(list, kins);
+                                    thr = min(list[MAXG - 1], keymax);
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+#pragma unroll
+                for (int d = 0; d < SWIN; d++) acc[e][d] = 0;
+        }
+    }
+
+    if (ref_ok) {
+        uint32_t* out = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
+#pragma unroll
+        for (int k = 0; k < MAXG; k += 4) {
+            uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
+            *reinterpret_cast<uint4*>(out + k) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic kernel: one wave per reference block, lanes share the 1331 candidates.  Used for the
 // clamped last grid position of an axis whose extent is not 8 (mod 4) (e.g. the 54^3 crops of
 // evaluate.py:201), and as an independent cross-check of the tile kernel in the parity tests.
@@ -410,8 +645,27 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // host launchers (called from exabm4d_api.cpp)
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
-                             uint32_t* keys, hipStream_t stream, int force_generic, int guarded) {
-    if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
+                             uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
+                             const uint16_t* vol16) {
+    // vol16 != nullptr: the volume's uint16 counts XOR 0x8000 in guarded scratch; the caller has
+    // checked that the integer kernel gives the float kernel's tables (keymax <= 2^24, nx even)
+    if (!force_generic && vol16 && g.az > 0 && g.ay > 0 && g.ax > 0) {
+        using Cube = TileShape16<8, 8>;
+        using Flat = TileShape16<4, 16>;
+        auto tiles = [&](int try_, int trx) {
+            return (long long)((g.ay + try_ - 1) / try_) * ((g.ax + trx - 1) / trx);
+        };
+        const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
+        const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
+        const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
+        dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
+        if (flat)
+            hipLaunchKernelGGL(bm_tile16_kernel<Flat>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx);
+        else
+            hipLaunchKernelGGL(bm_tile16_kernel<Cube>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    } else if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
         using Cube = TileShape<8, 8>;
         using Flat = TileShape<4, 16>;
         auto tiles = [&](int try_, int trx) {

@@ -114,6 +114,30 @@ struct OpCountsFromU16 {
         st8(out + i, v);
     }
 };
+// the same, plus the counts XOR 0x8000 (= v - 32768 as int16) for the integer block matching
+struct OpCountsFromU16Both {
+    const uint16_t* in;
+    float* out;
+    uint16_t* out16;
+    float offset;
+    __device__ void one(size_t i) const {
+        out[i] = (float)in[i] - offset;
+        out16[i] = (uint16_t)(in[i] ^ 0x8000u);
+    }
+    __device__ void eight(size_t i) const {
+        const uint4 r = *reinterpret_cast<const uint4*>(in + i);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[2 * k] = (float)(w[k] & 0xFFFFu) - offset;
+            v[2 * k + 1] = (float)(w[k] >> 16) - offset;
+        }
+        st8(out + i, v);
+        *reinterpret_cast<uint4*>(out16 + i) =
+            make_uint4(r.x ^ 0x80008000u, r.y ^ 0x80008000u, r.z ^ 0x80008000u, r.w ^ 0x80008000u);
+    }
+};
 struct OpNormalizeU16 {
     const float* num;
     const float* den;
@@ -333,7 +357,8 @@ hipError_t launch_chunk_hist(const uint16_t* vol, int nz, int ny, int nx, int cz
 // scatter: the denoised padded chunks' cores -> + offset -> clip -> rint -> u16 into the output.
 __global__ __launch_bounds__(EW_THREADS) void chunk_gather_kernel(const uint16_t* __restrict__ in,
                                                                   ChunkBatch cb, float offset,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out,
+                                                                  uint16_t* __restrict__ out16) {
     const size_t pvox = (size_t)cb.pz * cb.py * cb.px;
     const size_t total = pvox * (size_t)cb.count;
     for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total;
@@ -346,7 +371,9 @@ __global__ __launch_bounds__(EW_THREADS) void chunk_gather_kernel(const uint16_t
         const int gz = min(max(cb.z0 + bz * cb.cz - cb.lz + z, 0), cb.nz - 1);
         const int gy = min(max(cb.y0 + by * cb.cy - cb.ly + y, 0), cb.ny - 1);
         const int gx = min(max(cb.x0 + bx * cb.cx - cb.lx + x, 0), cb.nx - 1);
-        out[i] = (float)in[((size_t)gz * cb.ny + gy) * cb.nx + gx] - offset;
+        const unsigned v = in[((size_t)gz * cb.ny + gy) * cb.nx + gx];
+        out[i] = (float)v - offset;
+        if (out16) out16[i] = (uint16_t)(v ^ 0x8000u);
     }
 }
 __global__ __launch_bounds__(EW_THREADS) void chunk_scatter_kernel(const float* __restrict__ est,
@@ -368,10 +395,10 @@ __global__ __launch_bounds__(EW_THREADS) void chunk_scatter_kernel(const float* 
     }
 }
 hipError_t launch_chunk_gather(const uint16_t* in, const ChunkBatch& cb, float offset, float* out,
-                               hipStream_t s) {
+                               hipStream_t s, uint16_t* out16) {
     const size_t total = (size_t)cb.pz * cb.py * cb.px * (size_t)cb.count;
     const unsigned blocks = (unsigned)std::min<size_t>((total + EW_THREADS - 1) / EW_THREADS, 1u << 20);
-    hipLaunchKernelGGL(chunk_gather_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, in, cb, offset, out);
+    hipLaunchKernelGGL(chunk_gather_kernel, dim3(blocks), dim3(EW_THREADS), 0, s, in, cb, offset, out, out16);
     return hipGetLastError();
 }
 hipError_t launch_chunk_scatter(const float* est, const ChunkBatch& cb, float offset, uint16_t* out,
@@ -519,7 +546,10 @@ hipError_t launch_normalize(const float* num, const float* den, float* out, size
     return hipGetLastError();
 }
 hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, float offset,
-                                  hipStream_t s) {
+                                  hipStream_t s, uint16_t* out16) {
+    if (out16)
+        return launch_stream(OpCountsFromU16Both{in, out, out16, offset}, n,
+                             aligned16(in, out) && ((uintptr_t)out16 & 15) == 0, s);
     return launch_stream(OpCountsFromU16{in, out, offset}, n, aligned16(in, out), s);
 }
 hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,

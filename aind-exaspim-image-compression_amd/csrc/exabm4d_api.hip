@@ -36,6 +36,7 @@ struct exabm4d_ctx {
     int bm_guarded_copy = 0;   // exabm4d_set_option("bm_guarded_copy"): staged block matching on a guarded copy
     int stage_pairs = 1;       // exabm4d_set_option("stage_pairs"): two waves per group (HT stage)
     int profile = 0;           // exabm4d_set_option("profile")
+    int bm_int = 1;            // exabm4d_set_option("bm_int"): integer block matching on uint16 input
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
@@ -317,6 +318,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->stage_pairs = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "bm_int") == 0) {
+        ctx->bm_int = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "stage_chunks") == 0) {       // diagnostic: z chunks of the stage kernels
         g_stage_chunks = value > 0 ? value : 0;
         return EXABM4D_OK;
@@ -451,6 +456,37 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
     return EXABM4D_OK;
 }
 
+// Block matching on a uint16 volume the way the uint16 pipelines do it: fp32 counts and the biased
+// uint16 copy side by side in guarded scratch, integer tile kernel where its tables are the float
+// kernel's (else the float kernel), one-wave kernel for clamped last grid positions.
+int exabm4d_blockmatch_u16_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx, int batch,
+                               float sigma, float c_match, const exabm4d_params* p, uint32_t* keys) {
+    if (!ctx || !vol || !keys) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!(sigma > 0.0f) || !(c_match > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma and c_match must be > 0");
+    VolGeom g;
+    rc = make_geom(ctx, nz, ny, nx, batch, g);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)g.nvox * (size_t)batch;
+    const size_t fbytes = align256(n * sizeof(float));
+    rc = ensure_scratch(ctx, 2 * GUARD_BYTES + fbytes + align256(n * sizeof(uint16_t)));
+    if (rc) return rc;
+    char* base = static_cast<char*>(ctx->scratch);
+    float* f32 = reinterpret_cast<float*>(base + GUARD_BYTES);
+    uint16_t* u16 = reinterpret_cast<uint16_t*>(base + 2 * GUARD_BYTES + fbytes);
+    HIP_TRY(ctx, launch_counts_from_u16(vol, f32, n, 0.0f, ctx->stream, u16));
+    const double tau512 = (double)c_match * (double)sigma * (double)sigma * 512.0;
+    const bool use16 = ctx->bm_int && tau512 < 16777216.0 && (nx % 2) == 0 &&
+                       guarded_region_ok(ctx, u16, n * sizeof(uint16_t));
+    if (!guarded_region_ok(ctx, f32, n * sizeof(float)))
+        return fail(ctx, EXABM4D_ERR_INVALID, "internal: guarded volume without mapped slack around it");
+    HIP_TRY(ctx, launch_blockmatch(f32, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
+                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr));
+    return EXABM4D_OK;
+}
+
 int exabm4d_match_decode(const uint32_t* keys16, int rz, int ry, int rx, int ny, int nx,
                          int64_t* idx, float* dist, int* count) {
     if (!keys16 || !idx || !dist || !count) return fail(nullptr, EXABM4D_ERR_INVALID, "NULL argument");
@@ -527,7 +563,10 @@ struct PhaseTimer {
 static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, uint16_t* out_u16,
                         const VolGeom& g, int batch, float sigma, const exabm4d_params* p,
                         int stages, float clip_lo, float clip_hi, float u16_offset, char* scratch,
-                        int noisy_guarded) {
+                        int noisy_guarded, const uint16_t* noisy16 = nullptr) {
+    // noisy16: the same volume as uint16 counts XOR 0x8000, guarded like `noisy`, when the caller
+    // is a uint16 pipeline: stage-1 matching then runs in integer arithmetic (bm_tile16_kernel),
+    // provided its tables equal the float kernel's -- admission bound below 2^24, even row length
     // noisy_guarded: `noisy` lies inside the scratch allocation (mapped memory on both sides, see
     // ensure_scratch and bm_tile_kernel); a caller's own device buffer is not assumed to.
     const size_t n = (size_t)g.nvox * (size_t)batch;
@@ -559,8 +598,11 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);
+        const double tau512 = (double)p->c_match_ht * (double)sigma * (double)sigma * 512.0;
+        const bool use16 = noisy16 && ctx->bm_int && tau512 < 16777216.0 && (g.nx % 2) == 0 &&
+                           guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
         HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
-                                       ctx->force_generic_bm, noisy_guarded));
+                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
@@ -633,17 +675,19 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
     if (rc) return rc;
     const size_t n = (size_t)g.nvox * (size_t)batch;
     const size_t base = exabm4d_scratch_bytes(nz, ny, nx, batch, stages);
-    rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+    const size_t fbytes = align256(n * sizeof(float));
+    rc = ensure_scratch(ctx, base + fbytes + GUARD_BYTES + align256(n * sizeof(uint16_t)));
     if (rc) return rc;
     char* scratch = static_cast<char*>(ctx->scratch);
     float* noisy = reinterpret_cast<float*>(scratch + base);
+    uint16_t* noisy16 = reinterpret_cast<uint16_t*>(scratch + base + fbytes + GUARD_BYTES);
     ctx->ev_used[EXABM4D_PHASE_COUNTS_FROM_U16] = false;
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_COUNTS_FROM_U16);
-        HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream));
+        HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream, noisy16));
     }
     return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
-                        scratch, 1);
+                        scratch, 1, noisy16);
 }
 
 // Chunk-local mode: every chunk (core + halo, the halo cut off where the buffer ends) is denoised
@@ -685,7 +729,7 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                 cb.out_z0 = zc0;
                 const long long nchunks = (long long)rz.count * ry.count * rx.count;
                 const size_t per = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, 1, stages) +
-                                   align256((size_t)cb.pz * cb.py * cb.px * sizeof(float));
+                                   align256((size_t)cb.pz * cb.py * cb.px * (sizeof(float) + sizeof(uint16_t)));
                 long long bmax = (long long)(((size_t)ctx->chunk_budget_mb << 20) / per);
                 if (bmax < 1) bmax = 1;
                 if (bmax > 65535) bmax = 65535;
@@ -698,13 +742,15 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                     if (rc) return rc;
                     const size_t n = (size_t)g.nvox * (size_t)count;
                     const size_t base = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, count, stages);
-                    rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+                    const size_t fbytes = align256(n * sizeof(float));
+                    rc = ensure_scratch(ctx, base + fbytes + GUARD_BYTES + align256(n * sizeof(uint16_t)));
                     if (rc) return rc;
                     char* scratch = static_cast<char*>(ctx->scratch);
                     float* vol = reinterpret_cast<float*>(scratch + base);
-                    HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream));
+                    uint16_t* vol16 = reinterpret_cast<uint16_t*>(scratch + base + fbytes + GUARD_BYTES);
+                    HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream, vol16));
                     rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f,
-                                      scratch, 1);
+                                      scratch, 1, vol16);
                     if (rc) return rc;
                     HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
                 }

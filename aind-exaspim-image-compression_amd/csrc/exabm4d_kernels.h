@@ -19,7 +19,7 @@ struct TfDev {
 hipError_t launch_normalize(const float* num, const float* den, float* out, size_t n, float lo,
                             float hi, hipStream_t s);
 hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, float offset,
-                                  hipStream_t s);
+                                  hipStream_t s, uint16_t* out16 = nullptr);
 hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,
                                 float offset, hipStream_t s);
 hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,
@@ -57,7 +57,8 @@ int ssim3d_max_window();
 hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny, int nx, int w,
                          double C1, double C2, double* partials, double* out1, hipStream_t s);
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
-                             uint32_t* keys, hipStream_t stream, int force_generic, int guarded);
+                             uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
+                             const uint16_t* vol16 = nullptr);
 extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chunk count (0 = automatic)
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
@@ -83,7 +84,7 @@ struct ChunkBatch {
     int out_z0;              // output plane 0 is input plane out_z0
 };
 hipError_t launch_chunk_gather(const uint16_t* in, const ChunkBatch& cb, float offset, float* out,
-                               hipStream_t s);
+                               hipStream_t s, uint16_t* out16 = nullptr);
 hipError_t launch_chunk_scatter(const float* est, const ChunkBatch& cb, float offset, uint16_t* out,
                                 hipStream_t s);
 

@@ -165,6 +165,14 @@ size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages);
  * Sorted ascending; unused slots 0xFFFFFFFF.  c_match: threshold factor (c_match*sigma^2). */
 int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, int nx, int batch,
                            float sigma, float c_match, const exabm4d_params* p, uint32_t* keys);
+/* The same on uint16 counts, the way exabm4d_denoise_u16_dev / _chunked_u16_dev match in stage 1.
+ * The counts of a uint16 volume differ by exact integers whatever the offset, so block distances
+ * below 2^24 are exact in fp32 and equal their integer form: where c_match * sigma^2 * 512 < 2^24
+ * and nx is even the tiles run in integer arithmetic (v_pk_sub_i16 + v_dot2_i32_i16, half the
+ * vector-ALU cycles); the tables are bit-identical to exabm4d_blockmatch_dev on (float)vol.
+ * Option "bm_int" = 0 forces the float kernels (the parity tests compare both). */
+int exabm4d_blockmatch_u16_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, int ny, int nx, int batch,
+                               float sigma, float c_match, const exabm4d_params* p, uint32_t* keys);
 /* Host decode of one reference's 16 keys at grid position (rz,ry,rx) [voxels]:
  * idx[k] = linear voxel offset of the matched block corner, dist[k] = quantised S/512,
  * *count = number of valid entries (group size is the largest power of two <= count). */

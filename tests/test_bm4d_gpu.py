@@ -9,6 +9,8 @@ import pytest
 
 from util import psnr, synth_volume
 
+from aind_exaspim_image_compression import _native
+
 pytestmark = pytest.mark.gpu
 
 SIGMA = 24.0
@@ -312,3 +314,48 @@ def test_other_sigma_and_profile(ctx, oracle):
     got = ctx.denoise_f32_host(vol, SIGMA, params=p)
     want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
     assert psnr(got, want, 1000.0) > 80.0
+
+
+def _keys_u16(ctx, vol, sigma, c_match, batch=1):
+    shape = vol.shape[-3:]
+    g = [len(_native.grid_positions(n)) for n in shape]
+    d_vol = ctx.to_device(vol)
+    d_keys = ctx.alloc(batch * g[0] * g[1] * g[2] * 16 * 4)
+    try:
+        ctx.blockmatch_u16(d_vol, shape, sigma, c_match, d_keys, batch=batch)
+        ctx.sync()
+        return d_keys.download((batch, g[0], g[1], g[2], 16) if batch > 1 else (g[0], g[1], g[2], 16),
+                               np.uint32)
+    finally:
+        d_vol.free()
+        d_keys.free()
+
+
+@pytest.mark.parametrize("shape", [(24, 28, 32), (40, 44, 64), (26, 31, 22), (64, 64, 64), (33, 72, 130),
+                                   (24, 24, 25)])
+def test_integer_block_matching_equals_the_oracle(ctx, oracle, shape):
+    """Stage-1 matching of the uint16 pipelines (bm_tile16_kernel: saturating int16 differences,
+    v_dot2 accumulation) against the oracle on (float)v - offset: bit-exact tables, on aligned and
+    ragged extents (odd nx falls back to the float kernel), with saturating voxels (0 next to
+    65535: differences beyond int16), for both admission bounds, and with the integer path
+    switched off."""
+    vol = synth_volume(shape, seed=sum(shape), as_u16=True)[0]
+    vol.reshape(-1)[:: max(1, vol.size // 23)] = 65535
+    vol.reshape(-1)[5:: max(1, vol.size // 19)] = 0
+    f = vol.astype(np.float32) - np.float32(37.0)
+    for sigma, c_match in ((SIGMA, 3.0), (SIGMA, 0.6), (90.0, 3.0), (120.0, 3.0)):   # 120: bound > 2^24 -> float kernel
+        want = oracle.blockmatch(f, sigma, c_match)
+        np.testing.assert_array_equal(_keys_u16(ctx, vol, sigma, c_match), want)
+    ctx.set_option("bm_int", 0)
+    try:
+        np.testing.assert_array_equal(_keys_u16(ctx, vol, SIGMA, 3.0), oracle.blockmatch(f, SIGMA, 3.0))
+    finally:
+        ctx.set_option("bm_int", 1)
+
+
+def test_integer_block_matching_batch_of_patches(ctx, oracle):
+    """A batch of 64^3 patches (the 4 x 16 tile shape) through the integer kernel."""
+    vols = np.stack([synth_volume((64, 64, 64), seed=50 + i, as_u16=True)[0] for i in range(3)])
+    got = _keys_u16(ctx, vols, SIGMA, 3.0, batch=3)
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], oracle.blockmatch(vols[i].astype(np.float32) - 37.0, SIGMA, 3.0))
