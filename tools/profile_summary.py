@@ -16,7 +16,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PHASES = {           # bench phase -> (kernel-name fragment, launches of it per bench step)
     "counts_from_u16": "OpCountsFromU16",
-    "blockmatch_ht": "bm_tile_kernel",
+    "blockmatch_ht": "bm_tile16_kernel",     # uint16 pipelines: the integer tile kernel
     "blockmatch_wie": "bm_tile_kernel",
     "stage_ht": "stage_half_kernel<false>",
     "stage_wie": "stage_half_kernel<true>",
