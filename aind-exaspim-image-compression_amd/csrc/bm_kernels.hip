@@ -10,6 +10,7 @@
 // bm_tile_kernel exploits: one lane owns one cell, cell sums go through LDS, one lane owns one
 // reference block's running top-16 list.
 #include "exabm4d_kernels.h"
+#include <type_traits>
 
 namespace exabm4d {
 
@@ -331,10 +332,11 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 // matters and the same number can be formed in integer arithmetic.  A candidate is admitted only
 // below keymax <= 2^24 (checked by the launcher: c_match * sigma^2 * 512 < 2^24), so for every
 // candidate that can enter a match table the integer sum converted to float has exactly the bits
-// the float kernel produces, and everything else is rejected by both.  The integer form costs
-// half the vector-ALU cycles: v_pk_sub_i16 (saturating) forms two differences, v_dot2_i32_i16
-// (saturating) squares and accumulates both -- two 2-cycle instructions per two (voxel,
-// displacement) pairs against two 4-cycle packed-fp32 ones -- and a staged plane is half the bytes.
+// the float kernel produces, and everything else is rejected by both.  v_pk_sub_i16 (saturating)
+// forms two differences, v_dot2_i32_i16 (saturating) squares and accumulates both: the same two
+// instructions per two (voxel, displacement) pairs as the packed-fp32 form, and -- measured,
+// tools/dbg/valu_rate_bench.hip -- at the same ~4.3 cycles each; what the integer form saves is
+// LDS: a staged plane is half the bytes and a window row two ds_read_b64 instead of four b128.
 //
 // Input: the volume with every voxel XOR 0x8000 (= v - 32768 as int16), in the library's scratch
 // with mapped memory around it (written next to the fp32 counts by the uint16 pipelines).  The
@@ -432,10 +434,16 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 #pragma unroll
         for (int d = 0; d < SWIN; d++) acc[e][d] = 0;
 
-#pragma unroll 1
-    for (int step = 0; step < NSTEP; step++) {
-        const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
-        const int dylo = pass == 0 ? -RAD : 1;
+    // One step = one staged plane.  The first pass of a dz covers dy = -5..0 (six rows of sums), the
+    // second dy = 1..5 (five): the body is instantiated for both counts, so no cycles go into a
+    // twelfth, masked dy (1024^3: 117.7 -> 114.6 ms).  The float kernel keeps the single body with
+    // a masked row: it already sits at 252 registers and the second instantiation spills (131 ->
+    // 158 ms measured).
+    auto step_body = [&](auto NEc, const int step) {
+        constexpr int NEP = decltype(NEc)::value;                 // dy values of this pass
+        constexpr int NR0 = (NEP + 1) / 2;                        // ... of its first exchange round
+        const int z = step & 3, dz = (step >> 3) - RAD;
+        const int dylo = NEP == NE ? -RAD : 1;
         uint32_t* cur = pbuf_all[cz][step & 1];
         uint32_t* nxt = pbuf_all[cz][(step + 1) & 1];
 
@@ -457,8 +465,8 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 #pragma unroll
             for (int j = 0; j < 4; j++) wq[j] = *reinterpret_cast<const uint2*>(wrow + 2 * j);
 #pragma unroll
-            for (int rp = 0; rp < 3 + NE; rp++) {
-                if (rp + 1 < 3 + NE) {
+            for (int rp = 0; rp < 3 + NEP; rp++) {
+                if (rp + 1 < 3 + NEP) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         wn[j] = *reinterpret_cast<const uint2*>(wrow + (rp + 1) * (PSTR / 2) + 2 * j);
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int y = 0; y < 4; y++) {
                     const int e = rp - y;
-                    if (e >= 0 && e < NE) {
+                    if (e >= 0 && e < NEP) {
 #pragma unroll
                         for (int xp = 0; xp < 2; xp++) {
                             const s16x2 a = __builtin_bit_cast(s16x2, xp ? A[y].y : A[y].x);
@@ -498,9 +506,9 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
             const uint32_t* lo_w = cur + lane;
             const uint32_t* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;
 #pragma unroll
-            for (int e0 = 0; e0 < NE; e0 += NE / 2) {
+            for (int e0 = 0; e0 < NEP; e0 += NR0) {
 #pragma unroll
-                for (int e = e0; e < e0 + NE / 2; e++)
+                for (int e = e0; e < (e0 + NR0 < NEP ? e0 + NR0 : NEP); e++)
 #pragma unroll
                     for (int d = 0; d < SWIN; d++) {
                         // cell sums are capped at 2^27 so that eight of them cannot wrap; a capped
@@ -513,9 +521,9 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
                 __syncthreads();
                 if (ref_ok) {
 #pragma unroll
-                    for (int e = e0; e < e0 + NE / 2; e++) {
+                    for (int e = e0; e < (e0 + NR0 < NEP ? e0 + NR0 : NEP); e++) {
                         const int dy = dylo + e;
-                        if (dy <= RAD) {
+                        {
                             const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
                             const uint32_t cbase =
                                 1u + (uint32_t)(((dz + RAD) * SWIN + (dy + RAD)) * SWIN);
@@ -545,6 +553,13 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int d = 0; d < SWIN; d++) acc[e][d] = 0;
         }
+    };
+#pragma unroll 1
+    for (int step = 0; step < NSTEP; step++) {
+        if (((step >> 2) & 1) == 0)
+            step_body(std::integral_constant<int, NE>{}, step);
+        else
+            step_body(std::integral_constant<int, NE - 1>{}, step);
     }
 
     if (ref_ok) {
