@@ -101,6 +101,8 @@ SIGNATURES = {
                                   ctypes.POINTER(_I)]),
     "exabm4d_stage_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, c_vp, c_vp]),
     "exabm4d_normalize_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F, _F]),
+    "exabm4d_counts_from_u16_dev": (_I, [_CTX, c_vp, c_vp, _SZ, _F]),
+    "exabm4d_normalize_u16_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F]),
     "exabm4d_denoise_f32_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_chunked_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, _F, _F, _PP,
@@ -325,6 +327,15 @@ class Context:
         lo, hi = (1.0, 0.0) if clip is None else clip
         self._check(lib().exabm4d_normalize_dev(self.handle, _ptr(num), _ptr(den), _ptr(out), n,
                                                 float(lo), float(hi)))
+
+    def counts_from_u16(self, src, dst, n, offset):
+        """dst (fp32) = (float)src - offset: read_counts, data_handling.py:337-354"""
+        self._check(lib().exabm4d_counts_from_u16_dev(self.handle, _ptr(src), _ptr(dst), n, offset))
+
+    def normalize_u16(self, num, den, out, n, offset):
+        """out (uint16) = rint(clamp(num / den + offset, 0, 65535))"""
+        self._check(lib().exabm4d_normalize_u16_dev(self.handle, _ptr(num), _ptr(den), _ptr(out), n,
+                                                    offset))
 
     def denoise_f32(self, src, dst, shape, sigma, params=None, stages=2, clip=None, batch=1):
         p = params or default_params()

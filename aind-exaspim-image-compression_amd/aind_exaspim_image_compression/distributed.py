@@ -141,6 +141,15 @@ def denoise_slab(noisy, plan, sigma, stage1, stage2, dist=None, group=None):
     return out[plan.core]
 
 
+def denoise_slab_u16(raw, plan, offset, denoiser, dist=None, group=None):
+    """The uint16 pipeline of this rank's padded slab ``raw`` ([p1-p0, ny, nx] int16 view of the
+    counts) with the fused ends of ``exabm4d_denoise_u16_dev``: ``denoiser`` is a ``SlabDenoiser``.
+    Returns the owned planes (int16 view of uint16)."""
+    noisy, basic = denoiser.stage1_u16(raw, offset)
+    exchange_basic_halo(basic, plan, dist=dist, group=group)
+    return denoiser.stage2_u16(noisy, basic, offset)[plan.core]
+
+
 class SlabDenoiser:
     """The two stage callables of ``denoise_slab`` on one MI355X, through the staged C-ABI entry
     points (exabm4d_blockmatch_dev / exabm4d_stage_dev / exabm4d_normalize_dev), with all
@@ -182,6 +191,48 @@ class SlabDenoiser:
 
     def stage2(self, noisy, basic):
         return self._run(basic, self.params.c_match_wie, noisy, basic)
+
+    # ---- the uint16 pipeline of exabm4d_denoise_u16_dev, split at the halo exchange ---------------
+    def stage1_u16(self, raw, offset):
+        """``raw``: the padded slab's counts (an int16 view of the uint16 planes).  Returns
+        (noisy, basic): fp32 counts minus ``offset`` and the stage-1 estimate, both whole padded
+        slabs.  Matching runs on the uint16 planes themselves (integer kernel where it applies)."""
+        torch, ctx = self.torch, self.ctx
+        n = raw.numel()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            ctx.set_stream(stream.cuda_stream)
+            noisy = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+            basic = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+            ctx.counts_from_u16(raw, noisy, n, float(offset))
+            self.num.zero_()
+            self.den.zero_()
+            ctx.blockmatch_u16(raw, self.shape, self.sigma, self.params.c_match_ht, self.keys,
+                               self.params)
+            ctx.stage(noisy, None, self.keys, self.shape, self.sigma, self.num, self.den, self.params)
+            ctx.normalize(self.num, self.den, basic, n)
+            stream.synchronize()
+            ctx.reset_stream()
+        return noisy, basic
+
+    def stage2_u16(self, noisy, basic, offset):
+        """Stage 2 on the padded slab and the uint16 cast (+ offset, clamp, rint) of every plane;
+        returns an int16 view tensor like ``raw``."""
+        torch, ctx = self.torch, self.ctx
+        n = noisy.numel()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            ctx.set_stream(stream.cuda_stream)
+            self.num.zero_()
+            self.den.zero_()
+            ctx.blockmatch(basic, self.shape, self.sigma, self.params.c_match_wie, self.keys,
+                           self.params)
+            ctx.stage(noisy, basic, self.keys, self.shape, self.sigma, self.num, self.den, self.params)
+            out = torch.empty(self.shape, dtype=torch.int16, device=self.device)
+            ctx.normalize_u16(self.num, self.den, out, n, float(offset))
+            stream.synchronize()
+            ctx.reset_stream()
+        return out
 
 
 # ---- chunk-local mode across ranks (BASELINE.json config 4) -------------------------------------

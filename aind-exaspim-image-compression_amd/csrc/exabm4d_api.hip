@@ -543,6 +543,21 @@ int exabm4d_normalize_dev(exabm4d_ctx* ctx, const float* num, const float* den, 
     return EXABM4D_OK;
 }
 
+int exabm4d_counts_from_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, float* out, size_t n, float offset) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_counts_from_u16(in, out, n, offset, ctx->stream));
+    return EXABM4D_OK;
+}
+
+int exabm4d_normalize_u16_dev(exabm4d_ctx* ctx, const float* num, const float* den, uint16_t* out,
+                              size_t n, float offset) {
+    if (!ctx || !num || !den || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_normalize_u16(num, den, out, n, offset, ctx->stream));
+    return EXABM4D_OK;
+}
+
 // Bracket one phase of a pipeline call with events when profiling is on.
 struct PhaseTimer {
     exabm4d_ctx* ctx;

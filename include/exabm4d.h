@@ -189,6 +189,15 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
 int exabm4d_normalize_dev(exabm4d_ctx* ctx, const float* num, const float* den, float* out,
                           size_t n, float clip_lo, float clip_hi);
 
+/* The two ends of exabm4d_denoise_u16_dev as staged calls, for callers that run the stages
+ * themselves (z-slab sharding, distributed.py): out = (float)in - offset (read_counts,
+ * machine_learning/data_handling.py:337-354) ... */
+int exabm4d_counts_from_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, float* out, size_t n, float offset);
+/* ... and out = uint16(rint(clamp(num/den + offset, 0, 65535))) (np.clip of data_handling.py:333 and
+ * the cast of IntensityTransform.inverse, transforms.py:168-171). */
+int exabm4d_normalize_u16_dev(exabm4d_ctx* ctx, const float* num, const float* den, uint16_t* out,
+                              size_t n, float offset);
+
 /* ---- BM4D whole pipeline ------------------------------------------------------------------- */
 /* stages: 1 = hard-threshold only, 2 = hard-threshold + Wiener.  in/out may alias. */
 int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,

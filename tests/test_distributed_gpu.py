@@ -3,7 +3,8 @@ rendezvous, device tensors staged through the host in the halo exchange) and run
 (a) the exact slab mode -- SlabDenoiser stage callables, basic-estimate halo exchange -- and
 (b) the chunk-local mode of BASELINE.json config 4 -- raw input halo exchange overlapped with the
 interior chunk layers, ChunkedSlabDenoiser -- and the stitched results must equal the
-single-process device results."""
+single-process device results; (c) the uint16 form of the slab mode (fused conversion ends,
+integer matching on the uint16 planes) against exabm4d_denoise_u16_dev of the whole volume."""
 import os
 import socket
 import sys
@@ -38,7 +39,8 @@ def _worker(rank, world, port, tmp):
             sys.path.insert(0, p)
     from aind_exaspim_image_compression.distributed import (ChunkedSlabDenoiser, SlabDenoiser,
                                                             denoise_chunked_slab, denoise_slab,
-                                                            plan_chunk_slabs, plan_slabs)
+                                                            denoise_slab_u16, plan_chunk_slabs,
+                                                            plan_slabs)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
                             world_size=world)
     dev = torch.device("cuda", 0)
@@ -57,6 +59,11 @@ def _worker(rank, world, port, tmp):
     cden = ChunkedSlabDenoiser(SIGMA, OFFSET, dev, chunk=16, halo=8)
     cout = denoise_chunked_slab(raw, cplan, cden.run, chunk=16)
     np.save(os.path.join(tmp, f"cslab{rank}.npy"), cout.cpu().numpy().view(np.uint16))
+    # (c) exact slabs, uint16 pipeline
+    u_np, _ = synth_volume(SLAB_SHAPE, seed=43, as_u16=True)
+    uraw = torch.from_numpy(np.ascontiguousarray(u_np[plan.p0:plan.p1]).view(np.int16)).to(dev)
+    uout = denoise_slab_u16(uraw, plan, OFFSET, den)
+    np.save(os.path.join(tmp, f"uslab{rank}.npy"), uout.cpu().numpy().view(np.uint16))
     np.save(os.path.join(tmp, f"plans{rank}.npy"), np.array([plan.z0, plan.z1, cplan.z0, cplan.z1]))
     dist.barrier()
     dist.destroy_process_group()
@@ -70,12 +77,19 @@ def test_two_ranks_hip_compute(ctx, tmp_path):
     whole = ctx.denoise_f32_host(vol, SIGMA, stages=2)
     raw_np, _ = synth_volume(CHUNK_SHAPE, seed=42, as_u16=True)
     cwhole = denoise_chunked(raw_np, SIGMA, OFFSET, chunk=16, halo=8)
-    got, cgot = np.empty_like(whole), np.empty_like(cwhole)
+    u_np, _ = synth_volume(SLAB_SHAPE, seed=43, as_u16=True)
+    d_in, d_out = ctx.to_device(u_np), ctx.alloc(u_np.nbytes)
+    ctx.denoise_u16(d_in, d_out, SLAB_SHAPE, SIGMA, OFFSET)
+    uwhole = d_out.download(SLAB_SHAPE, np.uint16)
+    got, cgot, ugot = np.empty_like(whole), np.empty_like(cwhole), np.empty_like(uwhole)
     for r in range(world):
         z0, z1, c0, c1 = np.load(tmp_path / f"plans{r}.npy")
         got[z0:z1] = np.load(tmp_path / f"slab{r}.npy")
         cgot[c0:c1] = np.load(tmp_path / f"cslab{r}.npy")
+        ugot[z0:z1] = np.load(tmp_path / f"uslab{r}.npy")
     # 24-plane halo: identical up to the fp32 order of the aggregation sums
     np.testing.assert_allclose(got, whole, rtol=1e-4, atol=2e-3)
     d = np.abs(cgot.astype(np.int32) - cwhole.astype(np.int32))
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3
+    du = np.abs(ugot.astype(np.int32) - uwhole.astype(np.int32))
+    assert du.max() <= 1 and np.mean(du > 0) < 1e-3
