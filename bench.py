@@ -231,7 +231,9 @@ def bm4dnet_leg(edge, seed):
         "voxels_per_s": vol.size / dt,
         "unet_tflops": npatch * 109.639e9 / dt / 1e12,
         "extrapolated_1024_seconds": round(dt * 8000.0 / npatch, 1),
-        "extrapolation": "8000 / %d patches x measured time (same batch shape); not measured at 1024^3" % npatch,
+        "extrapolation": ("measured at 1024^3" if npatch == 8000 else
+                          "8000 / %d patches x measured time (same batch shape); `--bm4dnet 1024` measures it "
+                          "(29.5 s on an MI355X at the end of round 2, DESIGN.md 7.0)" % npatch),
     }
 
 
