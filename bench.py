@@ -51,7 +51,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 16 x 4-byte keys per reference block = 64 B / 64 voxels = 1 B/voxel.
 ALGO_BYTES_PER_VOXEL = {
     "counts_from_u16": 2 + 4,
-    "blockmatch_ht": 4 + 1,
+    "blockmatch_ht": 2 + 1,          # stage-1 matching reads the uint16 planes (integer kernel)
     "stage_ht": 1 + 4 + 8,
     "normalize_basic": 8 + 4,
     "blockmatch_wie": 4 + 1,
@@ -558,6 +558,17 @@ def main():
                 "peak_cycles": simd_cycles,
                 "frac": rec["valu_busy_cycles"] / simd_cycles,
             }
+        # every kernel of the step against both ceilings (same sources as above)
+        every = {}
+        for k, ms in sorted(kern.items(), key=lambda kv: -kv[1]):
+            r = profile_record(k, shape, ms) or {}
+            gbs = ALGO_BYTES_PER_VOXEL[k] * nvox / (ms * 1e-3) / 1e9
+            every[k] = {"avg_ms": ms, "achieved_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                        "traffic": r.get("hbm_bytes"),
+                        "valu_frac": (r["valu_busy_cycles"] / (1024 * 2.4e9 * ms * 1e-3)
+                                      if r.get("valu_busy_cycles") else None),
+                        "stale": r.get("stale")}
+        roofline["every_kernel"] = every
         result = {
             "metric": "denoised+encoded voxels/s on 1024^3 uint16",
             "value": world * nvox * args.steps / elapsed,
