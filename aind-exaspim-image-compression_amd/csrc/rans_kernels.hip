@@ -78,6 +78,9 @@ struct RowCursor {
     }
 };
 
+#ifndef EXABM4D_ENC_PP
+#define EXABM4D_ENC_PP 2        // byte planes per wave of the encoder (1: one wave per plane)
+#endif
 template <int TS>
 __device__ __forceinline__ uint32_t load_bits(const void* vol, size_t e) {
     if (TS == 2) return static_cast<const uint16_t*>(vol)[e];
@@ -158,17 +161,21 @@ __device__ __forceinline__ void normalize_plane(const uint32_t (&cnt)[4], uint32
 // ---- encode: one workgroup per chunk, wave p codes byte plane p into the chunk's slot ---------------
 // Slot layout (scratch, worst case per chunk): [0, 8 + 4 TS) header, then TS table regions of
 // HDR_TABLE bytes, then at g.slot_hdr TS stream regions of g.slot_plane bytes.
-template <int TS>
-__global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __restrict__ vol, CodecGeom g,
-                                                             const uint2* __restrict__ rcp_tab,
-                                                             uint8_t* __restrict__ slots,
-                                                             uint32_t* __restrict__ sizes) {
+// One wave codes PP byte planes of the chunk side by side: the element loads, the row cursor and the
+// loop are shared by the planes, and a lane carries PP independent rANS states (two chains in
+// flight instead of one).  The streams are those of the one-plane-per-wave form, byte for byte.
+template <int TS, int PP>
+__global__ __launch_bounds__(64 * TS / PP) void rans_encode_kernel(const void* __restrict__ vol, CodecGeom g,
+                                                                  const uint2* __restrict__ rcp_tab,
+                                                                  uint8_t* __restrict__ slots,
+                                                                  uint32_t* __restrict__ sizes) {
+    static_assert(TS % PP == 0, "whole planes per wave");
     __shared__ uint32_t hist[TS][256];
     __shared__ uint2 etab[TS][256];
     __shared__ uint32_t plane_bytes[TS];
     const int c = blockIdx.x;
     const uint32_t lane = lane_id();
-    const int p = threadIdx.x >> 6;
+    const int p0 = (threadIdx.x >> 6) * PP;           // first plane of this wave
     const ChunkBox b = chunk_box(g, c);
     const uint32_t n = b.n;
     const uint32_t rows = (n + 63u) >> 6;
@@ -179,115 +186,207 @@ __global__ __launch_bounds__(64 * TS) void rans_encode_kernel(const void* __rest
     uint8_t* slot = slots + (size_t)c * g.slot_bytes;
 
 #pragma unroll
-    for (int j = 0; j < 4; j++) hist[p][64 * j + lane] = 0u;
+    for (int q = 0; q < PP; q++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) hist[p0 + q][64 * j + lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // -- pass 1: byte histogram of this wave's plane -------------------------------------------------
+    // -- pass 1: byte histograms of this wave's planes ---------------------------------------------
+    // (RB1 rows' loads in flight together: one 128-byte row per load is far too little to keep the
+    // memory system busy with a load-use round trip per row)
     rc.xr = rc.y = rc.z = 0;
-    for (uint32_t r = 0; r < rows; r++) {
-        const uint32_t i = r * 64u + lane;
-        const bool act = i < n;
-        uint32_t s = 0;
-        if (act) {
-            const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
-            s = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
+    constexpr int RB1 = 8;
+    // A histogram does not care which lane sees which element: when the rows are whole and 4-byte
+    // aligned, a lane loads 16 bytes (8 uint16 / 4 int32) and the wave takes RPI rows per load.
+    const bool wide = fast && (TS == 4 || (g.nx % 2) == 0) && (((uintptr_t)vol + b.base * TS) % 4) == 0;
+    if (wide) {
+        constexpr int EPL = 16 / TS, LPR = 64 / EPL, RPI = 64 / LPR;
+        const uint32_t rpl = (uint32_t)b.ey * rc.rpx;                    // rows per chunk plane
+        for (uint32_t r0 = 0; r0 < rows; r0 += RPI) {
+            const uint32_t row = r0 + lane / LPR;
+            const bool act = row < rows;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (act) {
+                const uint32_t z = row / rpl, rem = row - z * rpl, y = rem / rc.rpx, xr = rem - y * rc.rpx;
+                const size_t off = ((size_t)z * g.ny + y) * g.nx + xr * 64u + (lane % LPR) * EPL;
+                w = *reinterpret_cast<const uint4*>(static_cast<const char*>(vol) + (b.base + off) * TS);
+            }
+            uint32_t bits[EPL];
+            if (TS == 2) {
+                const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int k = 0; k < EPL; k++) bits[k] = (k & 1) ? d[k / 2] >> 16 : d[k / 2] & 0xFFFFu;
+            } else {
+                const int32_t d[4] = {(int32_t)w.x, (int32_t)w.y, (int32_t)w.z, (int32_t)w.w};
+#pragma unroll
+                for (int k = 0; k < EPL; k++) bits[k % 4] = ((uint32_t)d[k % 4] << 1) ^ (uint32_t)(d[k % 4] >> 31);
+            }
+            const uint64_t am = __ballot(act);
+#pragma unroll
+            for (int q = 0; q < PP; q++) {
+                const int sh = 8 * (p0 + q);
+                const uint32_t s0 = __builtin_amdgcn_readfirstlane((bits[0] >> sh) & 255u);   // lane 0 is active
+                bool all = true;
+#pragma unroll
+                for (int k = 0; k < EPL; k++) all = all && ((bits[k] >> sh) & 255u) == s0;
+                if (__ballot(act && all) == am) {      // one symbol in all these rows: a single add
+                    if (lane == 0) atomicAdd(&hist[p0 + q][s0], (uint32_t)__popcll(am) * EPL);
+                } else if (act) {
+#pragma unroll
+                    for (int k = 0; k < EPL; k++) atomicAdd(&hist[p0 + q][(bits[k] >> sh) & 255u], 1u);
+                }
+            }
         }
-        if (fast) rc.next();
-        const uint64_t am = __ballot(act);
-        const uint32_t s0 = __builtin_amdgcn_readfirstlane(s);
-        const uint64_t same = __ballot(act && s == s0);
-        if (same == am) {                      // one symbol in the whole row: a single add
-            if (lane == (uint32_t)__builtin_ctzll(am)) atomicAdd(&hist[p][s0], (uint32_t)__popcll(am));
-        } else if (act) {
-            atomicAdd(&hist[p][s], 1u);
+    } else
+    for (uint32_t r0 = 0; r0 < rows; r0 += RB1) {
+        uint32_t bits[RB1];
+        uint64_t am[RB1];
+#pragma unroll
+        for (int k = 0; k < RB1; k++) {
+            const uint32_t i = (r0 + k) * 64u + lane;
+            const bool act = r0 + k < rows && i < n;
+            bits[k] = 0;
+            if (act) {
+                const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
+                bits[k] = load_bits<TS>(vol, b.base + off);
+            }
+            if (fast && r0 + k < rows) rc.next();
+            am[k] = __ballot(act);
+        }
+#pragma unroll
+        for (int k = 0; k < RB1; k++) {
+            if (am[k] == 0) continue;              // rows past the end (wave-uniform)
+            const bool act = (am[k] >> lane) & 1ull;
+#pragma unroll
+            for (int q = 0; q < PP; q++) {
+                const uint32_t s = (bits[k] >> (8 * (p0 + q))) & 255u;
+                const uint32_t s0 = __builtin_amdgcn_readlane(s, (int)__builtin_ctzll(am[k]));
+                const uint64_t same = __ballot(act && s == s0);
+                if (same == am[k]) {               // one symbol in the whole row: a single add
+                    if (lane == (uint32_t)__builtin_ctzll(am[k]))
+                        atomicAdd(&hist[p0 + q][s0], (uint32_t)__popcll(am[k]));
+                } else if (act) {
+                    atomicAdd(&hist[p0 + q][s], 1u);
+                }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // -- tables ------------------------------------------------------------------------------------
-    uint32_t cnt[4], F[4];
+    uint32_t nsym[PP];
 #pragma unroll
-    for (int j = 0; j < 4; j++) cnt[j] = hist[p][64 * j + lane];
-    normalize_plane(cnt, n, lane, F);
+    for (int q = 0; q < PP; q++) {
+        const int p = p0 + q;
+        uint32_t cnt[4], F[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) cnt[j] = hist[p][64 * j + lane];
+        normalize_plane(cnt, n, lane, F);
 
-    uint8_t* tab = slot + 8 + 4 * TS + p * HDR_TABLE;
-    uint32_t nsym = 0, cum = 0;
-    uint32_t C[4];
+        uint8_t* tab = slot + 8 + 4 * TS + p * HDR_TABLE;
+        uint32_t ns = 0, cum = 0;
+        uint32_t C[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint64_t pm = __ballot(F[j] != 0u);
-        if (lane == 0) reinterpret_cast<uint64_t*>(tab)[j] = pm;
-        if (F[j]) reinterpret_cast<uint16_t*>(tab + 32)[nsym + rank_below(pm)] = (uint16_t)F[j];
-        nsym += (uint32_t)__popcll(pm);
-        C[j] = cum + wave_excl_scan(F[j], lane);
-        cum += wave_sum(F[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        uint2 e = make_uint2(0u, 0u);
-        if (F[j]) {
-            const uint2 rs = rcp_tab[F[j]];    // {reciprocal, shift}
-            const uint32_t bias = F[j] == 1u ? C[j] + RANS_M - 1u : C[j];
-            e.x = F[j] | (bias << 13) | (rs.y << 26);
-            e.y = rs.x;
+        for (int j = 0; j < 4; j++) {
+            const uint64_t pm = __ballot(F[j] != 0u);
+            if (lane == 0) reinterpret_cast<uint64_t*>(tab)[j] = pm;
+            if (F[j]) reinterpret_cast<uint16_t*>(tab + 32)[ns + rank_below(pm)] = (uint16_t)F[j];
+            ns += (uint32_t)__popcll(pm);
+            C[j] = cum + wave_excl_scan(F[j], lane);
+            cum += wave_sum(F[j]);
         }
-        etab[p][64 * j + lane] = e;
+        nsym[q] = ns;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint2 e = make_uint2(0u, 0u);
+            if (F[j]) {
+                const uint2 rs = rcp_tab[F[j]];    // {reciprocal, shift}
+                const uint32_t bias = F[j] == 1u ? C[j] + RANS_M - 1u : C[j];
+                e.x = F[j] | (bias << 13) | (rs.y << 26);
+                e.y = rs.x;
+            }
+            etab[p][64 * j + lane] = e;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // -- pass 2: rows from the last to the first ----------------------------------------------------------
-    uint32_t nwords = 0;
-    if (nsym > 1) {
-        uint16_t* out = reinterpret_cast<uint16_t*>(slot + g.slot_hdr + (size_t)p * g.slot_plane);
-        uint32_t x = RANS_L;
+    uint32_t nwords[PP], x[PP];
+    uint16_t* out[PP];
+    bool any_coded = false;
+#pragma unroll
+    for (int q = 0; q < PP; q++) {
+        nwords[q] = 0;
+        x[q] = RANS_L;
+        out[q] = reinterpret_cast<uint16_t*>(slot + g.slot_hdr + (size_t)(p0 + q) * g.slot_plane);
+        any_coded = any_coded || nsym[q] > 1;
+    }
+#ifdef EXABM4D_ENC_SKIP2
+    any_coded = false;      // timing probe: histogram + tables only
+#endif
+    if (any_coded) {
         constexpr int RB = 8;
         if (fast && rows) rc.seek(rows - 1);
         for (uint32_t rb = ((rows + RB - 1) / RB) * RB; rb > 0; rb -= RB) {
-            uint32_t sym[RB];
-            uint2 e[RB];
+            uint32_t bits[RB];
+            bool live[RB];
 #pragma unroll
             for (int k = 0; k < RB; k++) {
                 const uint32_t r = rb - 1 - k;
                 const uint32_t i = r * 64u + lane;
-                sym[k] = 0xFFFFFFFFu;
+                bits[k] = 0;
+                live[k] = false;
                 if (r < rows) {
                     if (i < n) {
                         const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
-                        sym[k] = (load_bits<TS>(vol, b.base + off) >> (8 * p)) & 255u;
+                        bits[k] = load_bits<TS>(vol, b.base + off);
+                        live[k] = true;
                     }
                     if (fast) rc.prev();
                 }
             }
 #pragma unroll
-            for (int k = 0; k < RB; k++) e[k] = etab[p][sym[k] & 255u];
+            for (int q = 0; q < PP; q++) {
+                if (nsym[q] <= 1) continue;        // a constant plane has no stream (wave-uniform)
+                uint2 e[RB];
 #pragma unroll
-            for (int k = 0; k < RB; k++) {
-                const bool act = sym[k] != 0xFFFFFFFFu;
-                const uint32_t f = e[k].x & 0x1FFFu;
-                const bool emit = act && x >= (f << 19);
-                const uint64_t em = __ballot(emit);
-                if (emit) {
-                    out[nwords + rank_below(em)] = (uint16_t)(x & 0xFFFFu);
-                    x >>= 16;
-                }
-                nwords += (uint32_t)__popcll(em);
-                if (act) {
-                    const uint32_t q = __umulhi(x, e[k].y) >> (e[k].x >> 26);
-                    x = x + ((e[k].x >> 13) & 0x1FFFu) + q * (RANS_M - f);
+                for (int k = 0; k < RB; k++) e[k] = etab[p0 + q][(bits[k] >> (8 * (p0 + q))) & 255u];
+#pragma unroll
+                for (int k = 0; k < RB; k++) {
+                    const bool act = live[k];
+                    const uint32_t f = e[k].x & 0x1FFFu;
+                    const bool emit = act && x[q] >= (f << 19);
+                    const uint64_t em = __ballot(emit);
+                    if (emit) {
+                        out[q][nwords[q] + rank_below(em)] = (uint16_t)(x[q] & 0xFFFFu);
+                        x[q] >>= 16;
+                    }
+                    nwords[q] += (uint32_t)__popcll(em);
+                    if (act) {
+                        const uint32_t qd = __umulhi(x[q], e[k].y) >> (e[k].x >> 26);
+                        x[q] = x[q] + ((e[k].x >> 13) & 0x1FFFu) + qd * (RANS_M - f);
+                    }
                 }
             }
         }
-        out[nwords + 2 * lane] = (uint16_t)(x & 0xFFFFu);       // low word, high word per lane
-        out[nwords + 2 * lane + 1] = (uint16_t)(x >> 16);
-        nwords += 128;
+#pragma unroll
+        for (int q = 0; q < PP; q++)
+            if (nsym[q] > 1) {
+                out[q][nwords[q] + 2 * lane] = (uint16_t)(x[q] & 0xFFFFu);       // low word, high word per lane
+                out[q][nwords[q] + 2 * lane + 1] = (uint16_t)(x[q] >> 16);
+                nwords[q] += 128;
+            }
     }
     if (lane == 0) {
-        reinterpret_cast<uint32_t*>(slot + 8)[p] = nwords;
-        plane_bytes[p] = 32u + 2u * nsym + 2u * nwords;
-        if (p == 0) {
+#pragma unroll
+        for (int q = 0; q < PP; q++) {
+            reinterpret_cast<uint32_t*>(slot + 8)[p0 + q] = nwords[q];
+            plane_bytes[p0 + q] = 32u + 2u * nsym[q] + 2u * nwords[q];
+        }
+        if (p0 == 0) {
             slot[0] = 'E';
             slot[1] = 'X';
             slot[2] = 1;
@@ -586,10 +685,10 @@ hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_
                               uint8_t* out, hipStream_t s) {
     const uint2* rt = reinterpret_cast<const uint2*>(rcp_tab);
     if (g.ts == 2)
-        hipLaunchKernelGGL(rans_encode_kernel<2>, dim3((unsigned)g.nchunks), dim3(128), 0, s, vol, g, rt,
+        hipLaunchKernelGGL((rans_encode_kernel<2, EXABM4D_ENC_PP>), dim3((unsigned)g.nchunks), dim3(128 / EXABM4D_ENC_PP), 0, s, vol, g, rt,
                            slots, sizes);
     else
-        hipLaunchKernelGGL(rans_encode_kernel<4>, dim3((unsigned)g.nchunks), dim3(256), 0, s, vol, g, rt,
+        hipLaunchKernelGGL((rans_encode_kernel<4, EXABM4D_ENC_PP>), dim3((unsigned)g.nchunks), dim3(256 / EXABM4D_ENC_PP), 0, s, vol, g, rt,
                            slots, sizes);
     hipLaunchKernelGGL(rans_scan_kernel, dim3(1), dim3(1024), 0, s, sizes, g.nchunks, offsets, totals);
     if (out) {
