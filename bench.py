@@ -237,25 +237,12 @@ def bm4dnet_leg(edge, seed):
     }
 
 
-def run_slabs(args, rank, local_rank, world, dist):
-    """N ranks, ONE volume of N*size planes: every rank holds its z-slab plus a 24-plane halo,
-    runs stage 1 (uint16 matching), exchanges the basic estimate's halo with its slab neighbours
-    (RCCL isend / irecv; 24 planes = 100 MB per neighbour at 1024^2, ~2 ms over xGMI against a
-    ~0.7 s step, so it is not overlapped), runs stage 2, and quantises + encodes its own planes
-    like the single-GPU step.  Weak scaling (size^3 voxels per rank)."""
+def torch_encode_legs(ctx, own, dev):
+    """The metric's encode legs on a rank's own planes held in a torch tensor (slab / chunk modes):
+    lossless EXAC of the uint16 planes, 8^3 DCT quantiser, EXAC of the indices; everything stays in
+    HBM.  Returns (encode(out), sizes of the lossless chunks)."""
     import torch
     from aind_exaspim_image_compression import _native
-    from aind_exaspim_image_compression.distributed import (SlabDenoiser, denoise_slab_u16,
-                                                            plan_slabs)
-    n = args.size
-    shape = (n * world, n, n)
-    plan = plan_slabs(shape[0], world, rank)
-    dev = torch.device("cuda", local_rank)
-    host = synth_u16(shape, seed=2000, z_range=(plan.p0, plan.p1))
-    raw = torch.from_numpy(host.view(np.int16)).to(dev)
-    den = SlabDenoiser(host.shape, SIGMA, dev)
-    ctx = den.ctx
-    own = (plan.z1 - plan.z0, n, n)
     nchunks = int(np.prod([-(-m // c) for m, c in zip(own, CHUNK)]))
     cap16 = _native.codec_volume_bound(2, own, CHUNK)
     enc16 = torch.empty(cap16, dtype=torch.uint8, device=dev)
@@ -270,15 +257,41 @@ def run_slabs(args, rank, local_rank, world, dist):
     off32 = torch.empty(nchunks_i + 1, dtype=torch.int64, device=dev)
     sz32 = torch.empty(nchunks_i, dtype=torch.int32, device=dev)
 
+    def encode(out):
+        ctx.codec_encode(out, 2, own, CHUNK, out=enc16, out_capacity=cap16, offsets=off16,
+                         sizes=sz16, totals=False)
+        ctx.dctq_forward(out, own, Q_STEP, idx)
+        ctx.codec_encode(idx, 4, idx_shape, idx_chunk, out=enc32, out_capacity=cap32,
+                         offsets=off32, sizes=sz32, totals=False)
+        ctx.sync()
+
+    return encode, sz16
+
+
+def run_slabs(args, rank, local_rank, world, dist):
+    """N ranks, ONE volume of N*size planes: every rank holds its z-slab plus a 24-plane halo,
+    runs stage 1 (uint16 matching), exchanges the basic estimate's halo with its slab neighbours
+    (RCCL isend / irecv; 24 planes = 100 MB per neighbour at 1024^2, ~2 ms over xGMI against a
+    ~0.7 s step, so it is not overlapped), runs stage 2, and quantises + encodes its own planes
+    like the single-GPU step.  Weak scaling (size^3 voxels per rank)."""
+    import torch
+    from aind_exaspim_image_compression.distributed import (SlabDenoiser, denoise_slab_u16,
+                                                            plan_slabs)
+    n = args.size
+    shape = (n * world, n, n)
+    plan = plan_slabs(shape[0], world, rank)
+    dev = torch.device("cuda", local_rank)
+    host = synth_u16(shape, seed=2000, z_range=(plan.p0, plan.p1))
+    raw = torch.from_numpy(host.view(np.int16)).to(dev)
+    den = SlabDenoiser(host.shape, SIGMA, dev)
+    ctx = den.ctx
+    own = (plan.z1 - plan.z0, n, n)
+    encode, sz16 = torch_encode_legs(ctx, own, dev)
+
     def step():
         out = denoise_slab_u16(raw, plan, OFFSET, den, dist=dist).contiguous()
         if not args.no_encode:
-            ctx.codec_encode(out, 2, own, CHUNK, out=enc16, out_capacity=cap16, offsets=off16,
-                             sizes=sz16, totals=False)
-            ctx.dctq_forward(out, own, Q_STEP, idx)
-            ctx.codec_encode(idx, 4, idx_shape, idx_chunk, out=enc32, out_capacity=cap32,
-                             offsets=off32, sizes=sz32, totals=False)
-            ctx.sync()
+            encode(out)
         return out
 
     def barrier():
@@ -340,10 +353,15 @@ def run_chunks(args, rank, local_rank, world, dist):
     own = torch.from_numpy(host.view(np.int16)).to(dev)
     raw = torch.zeros((plan.p1 - plan.p0, n, n), dtype=torch.int16, device=dev)
     den = ChunkedSlabDenoiser(SIGMA, OFFSET, dev, chunk=chunk, halo=halo)
+    own_shape = (plan.z1 - plan.z0, n, n)
+    encode, sz16 = torch_encode_legs(den.ctx, own_shape, dev)
 
     def step():
         raw[plan.core] = own                   # only the owned planes are known before the exchange
-        return denoise_chunked_slab(raw, plan, den.run, chunk=chunk, dist=dist)
+        out = denoise_chunked_slab(raw, plan, den.run, chunk=chunk, dist=dist).contiguous()
+        if not args.no_encode:
+            encode(out)
+        return out
 
     def barrier():
         torch.cuda.synchronize()
@@ -376,9 +394,13 @@ def run_chunks(args, rank, local_rank, world, dist):
             "config": {"workload": f"{shape[0]}x{n}x{n} uint16 volume, chunk-local two-stage BM4D: "
                                    f"{chunk}^3 cores + {halo}-voxel halo, {world} z-slab(s) of whole "
                                    "chunk layers, raw-input halo exchange overlapped with interior layers",
-                       "volume": list(shape), "stages": 2, "encode": "none",
+                       "volume": list(shape), "stages": 2,
+                       "encode": "none" if args.no_encode else
+                       f"lossless EXAC + 8^3 DCT q={Q_STEP:g} + EXAC of the indices, on the own planes",
                        "sharding": "chunk layers per rank, RCCL point-to-point exchange of 8 input planes"},
             "residual_std": float(resid.std()),
+            "rank0_lossless_cratio": None if args.no_encode else
+            round(2.0 * float(np.prod(own_shape)) / float(sz16.sum().item()), 2),
         }), flush=True)
     if dist is not None:
         dist.barrier()
