@@ -1,7 +1,7 @@
 """Randomised differential run, HIP path against the oracle (a tool, not a test: run it on a GPU box
 under `timeout`):
 
-    python tools/fuzz_parity.py [seconds=120] [seed=0]
+    python tools/fuzz_parity.py [seconds=120] [seed=0] [max_edge=72]
 
 Every iteration draws a shape (8..72 per axis, ragged and even / odd row lengths), a data regime
 (structure + noise, white noise, extremes 0 / 65535, constant, sparse), sigma and offset, and checks
@@ -57,12 +57,13 @@ def draw_volume(rng, shape):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    max_edge = int(sys.argv[3]) if len(sys.argv) > 3 else 72
     ctx = _native.context(0)
     codec = ShuffleRansCodec()
     t0, it = time.time(), 0
     while time.time() - t0 < budget:
         it += 1
-        shape = tuple(int(rng.integers(8, 73)) for _ in range(3))
+        shape = tuple(int(rng.integers(8, max_edge + 1)) for _ in range(3))
         if rng.random() < 0.3:
             shape = shape[:2] + (shape[2] // 2 * 2,)
         name, vol = draw_volume(rng, shape)
