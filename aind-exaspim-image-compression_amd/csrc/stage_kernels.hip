@@ -786,7 +786,10 @@ __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict_
                                                 const TileGeom& tg, const VolGeom& g, int lane) {
     constexpr int REG = C::COLS;
     ring_t* plane = ring + ((z + 5) % C::NPL) * C::PS;
-    constexpr int N = C::ROWS * REG, U = 4;   // four LDS reads in flight per lane
+    // LDS reads in flight per lane: six take a 22 x 30 plane in two rounds (four: three rounds, 171.6 /
+    // 231.5 ms against 169.8 / 230.1 -- the waves at the ring gate wait for this flush; eleven, one
+    // round, costs the Wiener kernel its registers: 275 ms)
+    constexpr int N = C::ROWS * REG, U = 6;
     for (int rem0 = lane; rem0 < N; rem0 += 64 * U) {
         ring_t v[U];
 #pragma unroll
