@@ -807,6 +807,37 @@ __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict_
     }
 }
 
+// Cooperative flush of a closed layer's planes (hard-threshold kernel).  The closing wave opens the
+// flush -- lock[3] = planes done = 0, then lock[2] = (layer + 1) << 16: generation and next plane in
+// ONE word -- and takes planes like everybody else; waves waiting at the ring gate take planes too.
+// A taker draws with one fetch-add, so the index it gets provably belongs to the generation that
+// came with it (a closed word has generation 0: the draw is void; a taker looks before it draws, so
+// at most one void draw per wave lands on a closed word -- far from its 16 bits).  The closer waits
+// for lock[3] to reach the plane count, closes the word and retires the layer.  Returns whether a
+// plane was flushed.
+#ifndef EXABM4D_HELP_FLUSH
+#define EXABM4D_HELP_FLUSH 1
+#endif
+template <class C>
+__device__ __forceinline__ bool flush_take(int* lock, ring_t* ring, float* __restrict__ num, const TileGeom& tg,
+                                           const VolGeom& g, int izb, int lane) {
+    int w = lane == 0 ? __hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+    if ((__builtin_amdgcn_readfirstlane(w) >> 16) == 0) return false;
+    w = lane == 0 ? __hip_atomic_fetch_add(lock + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+    w = __builtin_amdgcn_readfirstlane(w);
+    const int gen = w >> 16, i = w & 0xFFFF;
+    if (gen == 0) return false;
+    const int iz = izb + gen - 1;
+    const int z0 = grid_pos(iz, g.az, g.nz), zn = grid_pos(iz + 1, g.az, g.nz);
+    if (i >= zn - z0) return false;
+    cbar();
+    flush_num_plane<C>(ring, num, z0 - RAD + i, tg, g, lane);
+    cbar();
+    if (lane == 0) __hip_atomic_fetch_add(lock + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    cbar();
+    return true;
+}
+
 // Wiener counterparts.  The noisy and the basic-estimate groups keep separate spectra, both in the
 // hard-threshold layout (S[jp][2 kl + c] = coefficient plane 2 jp + c of local block kl), so that
 // (i) blocks (kl, kl + 1) of one volume are the two packed streams of a transform, exactly as in
@@ -860,13 +891,15 @@ __device__ __forceinline__ bool process_half_group(
     const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, ring_t* ring,
     float* __restrict__ cvol, f2* tb,
     f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int& seen, int layer, int target,
-    int lane, long long g_nvox
+    int lane, long long g_nvox, float* __restrict__ num, const VolGeom& g, int izb
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
 #endif
     ) {
     using C = HalfCfg<WIENER>;
     constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, REG = C::COLS;
+    constexpr bool HELP_FLUSH = !WIENER && EXABM4D_HELP_FLUSH;   // (the Wiener kernel has no registers for it
+                                                                 //  and waits 1.5 % of its time at the gate)
     constexpr int NP = WIENER ? 8 : 4;         // f2 values per lane swapped with the partner
     const int hi = lane >> 3, lo = lane & 7;
     STAMP(t0);
@@ -1134,12 +1167,26 @@ __device__ __forceinline__ bool process_half_group(
             const int need = layer + 1 - (HNPL - 5 - t + 3) / 4;
             if (seen < need) {
                 cbar();
-                int v = 0;
-                if (lane == 0) {
-                    while ((v = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
-                        __builtin_amdgcn_s_sleep(8);
+                if constexpr (HELP_FLUSH) {
+                    // The layer this block waits for retires when its planes have left the ring: a
+                    // waiting wave takes planes of the open flush (protocol: flush_take below).
+                    for (;;) {
+                        int v = lane == 0 ? __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+                        v = __builtin_amdgcn_readfirstlane(v);
+                        if (v >= need) {
+                            seen = v;
+                            break;
+                        }
+                        if (!flush_take<C>(lock, ring, num, tg, g, izb, lane)) __builtin_amdgcn_s_sleep(4);
+                    }
+                } else {
+                    int v = 0;
+                    if (lane == 0) {
+                        while ((v = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+                            __builtin_amdgcn_s_sleep(8);
+                    }
+                    seen = __builtin_amdgcn_readfirstlane(v);
                 }
-                seen = __builtin_amdgcn_readfirstlane(v);
                 cbar();
             }
         };
@@ -1330,7 +1377,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
 #endif
             const bool closer = process_half_group<WIENER>(
                 noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, ring, cvol, tb,
-                partner_tb, lock, sync, cnt, wave, seq, seen, layer, 2 * nrefs, lane, g.nvox
+                partner_tb, lock, sync, cnt, wave, seq, seen, layer, 2 * nrefs, lane, g.nvox, num, g, izb
 #ifdef EXABM4D_STAMPS
                 , st
 #endif
@@ -1350,7 +1397,23 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
                 cbar();
                 if (iz + 1 < ize) {
                     const int zn = grid_pos(iz + 1, g.az, g.nz);
-                    for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane<C>(ring, num, z, tg, g, lane);
+                    if constexpr (!WIENER && EXABM4D_HELP_FLUSH) {
+                        if (lane == 0) {
+                            __hip_atomic_store(lock + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(lock + 2, (layer + 1) << 16, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        cbar();
+                        while (flush_take<C>(lock, ring, num, tg, g, izb, lane)) {
+                        }
+                        if (lane == 0) {
+                            while (__hip_atomic_load(lock + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < zn - z0)
+                                __builtin_amdgcn_s_sleep(1);
+                            __hip_atomic_store(lock + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    } else {
+                        for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane<C>(ring, num, z, tg, g, lane);
+                    }
                 }
                 cbar();
                 if (lane == 0)
