@@ -1166,6 +1166,7 @@ __device__ __forceinline__ bool process_half_group(
             const int t = __builtin_amdgcn_readlane(my_dz, k) + 7;
             const int need = layer + 1 - (HNPL - 5 - t + 3) / 4;
             if (seen < need) {
+                STAMP(tg0);
                 cbar();
                 if constexpr (HELP_FLUSH) {
                     // The layer this block waits for retires when its planes have left the ring: a
@@ -1188,6 +1189,8 @@ __device__ __forceinline__ bool process_half_group(
                     seen = __builtin_amdgcn_readfirstlane(v);
                 }
                 cbar();
+                STAMP(tg1);
+                STAMP_ADD(3, tg0, tg1);
             }
         };
         STAMP(t3);
