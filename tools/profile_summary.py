@@ -22,8 +22,8 @@ PHASES = {           # bench phase -> (kernel-name fragment, launches of it per 
     "stage_wie": "stage_half_kernel<true>",
     "normalize_basic": "normalize_kernel",
     "normalize_out": "OpNormalizeU16",
-    "encode_u16": "rans_encode_kernel<2>",
-    "encode_idx": "rans_encode_kernel<4>",
+    "encode_u16": "rans_encode_kernel<2,",
+    "encode_idx": "rans_encode_kernel<4,",
     "dct_quantise": "dctq_forward",
 }
 
