@@ -87,7 +87,9 @@ def main():
         got = d_out.download(shape, np.uint16)
         ref = O.bm4d_u16(vol, sigma, offset)
         d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
-        ok_pipe = d.max() <= 1 and np.mean(d > 0) < 5e-3
+        # one count where the two fp32 summation orders round apart; an offset with fraction .5
+        # puts every integer-valued estimate of a flat region exactly on a rounding tie
+        ok_pipe = d.max() <= 1 and np.mean(d > 0) < (2e-2 if offset != int(offset) else 5e-3)
         del f
 
         # chunk coder on the denoised volume, random chunk grid
