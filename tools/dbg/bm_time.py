@@ -1,6 +1,6 @@
 """time exabm4d_blockmatch_u16_dev alone (no stages): python tools/dbg/bm_time.py [edge]"""
 import os, sys
-import numpy as np
+
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "aind-exaspim-image-compression_amd"))
 from aind_exaspim_image_compression import _native
