@@ -78,6 +78,9 @@ struct RowCursor {
     }
 };
 
+#ifndef EXABM4D_ENC_NC
+#define EXABM4D_ENC_NC 2        // copies of the encoder's histogram counters (power of two; 1: 6.3 + 8.4 ms, 2: 5.0 + 8.4, 4: 5.4 + 11.0 -- LDS per workgroup)
+#endif
 #ifndef EXABM4D_ENC_PP
 #define EXABM4D_ENC_PP 2        // byte planes per wave of the encoder (1: one wave per plane)
 #endif
@@ -170,7 +173,10 @@ __global__ __launch_bounds__(64 * TS / PP) void rans_encode_kernel(const void* _
                                                                   uint8_t* __restrict__ slots,
                                                                   uint32_t* __restrict__ sizes) {
     static_assert(TS % PP == 0, "whole planes per wave");
-    __shared__ uint32_t hist[TS][256];
+    // NC interleaved copies of every counter (copy = lane mod NC): the lanes of a wave that meet on
+    // one symbol of a skewed plane spread over NC addresses in NC different banks
+    constexpr int NC = EXABM4D_ENC_NC;
+    __shared__ uint32_t hist[TS][256 * NC];
     __shared__ uint2 etab[TS][256];
     __shared__ uint32_t plane_bytes[TS];
     const int c = blockIdx.x;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64 * TS / PP) void rans_encode_kernel(const void* _
 #pragma unroll
     for (int q = 0; q < PP; q++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) hist[p0 + q][64 * j + lane] = 0u;
+        for (int j = 0; j < 4 * NC; j++) hist[p0 + q][64 * j + lane] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -231,10 +237,11 @@ __global__ __launch_bounds__(64 * TS / PP) void rans_encode_kernel(const void* _
 #pragma unroll
                 for (int k = 0; k < EPL; k++) all = all && ((bits[k] >> sh) & 255u) == s0;
                 if (__ballot(act && all) == am) {      // one symbol in all these rows: a single add
-                    if (lane == 0) atomicAdd(&hist[p0 + q][s0], (uint32_t)__popcll(am) * EPL);
+                    if (lane == 0) atomicAdd(&hist[p0 + q][s0 * NC], (uint32_t)__popcll(am) * EPL);
                 } else if (act) {
 #pragma unroll
-                    for (int k = 0; k < EPL; k++) atomicAdd(&hist[p0 + q][(bits[k] >> sh) & 255u], 1u);
+                    for (int k = 0; k < EPL; k++)
+                        atomicAdd(&hist[p0 + q][((bits[k] >> sh) & 255u) * NC + (lane & (NC - 1))], 1u);
                 }
             }
         }
@@ -265,9 +272,9 @@ __global__ __launch_bounds__(64 * TS / PP) void rans_encode_kernel(const void* _
                 const uint64_t same = __ballot(act && s == s0);
                 if (same == am[k]) {               // one symbol in the whole row: a single add
                     if (lane == (uint32_t)__builtin_ctzll(am[k]))
-                        atomicAdd(&hist[p0 + q][s0], (uint32_t)__popcll(am[k]));
+                        atomicAdd(&hist[p0 + q][s0 * NC], (uint32_t)__popcll(am[k]));
                 } else if (act) {
-                    atomicAdd(&hist[p0 + q][s], 1u);
+                    atomicAdd(&hist[p0 + q][s * NC + (lane & (NC - 1))], 1u);
                 }
             }
         }
@@ -282,7 +289,11 @@ __global__ __launch_bounds__(64 * TS / PP) void rans_encode_kernel(const void* _
         const int p = p0 + q;
         uint32_t cnt[4], F[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) cnt[j] = hist[p][64 * j + lane];
+        for (int j = 0; j < 4; j++) {
+            cnt[j] = 0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) cnt[j] += hist[p][(64 * j + lane) * NC + c];
+        }
         normalize_plane(cnt, n, lane, F);
 
         uint8_t* tab = slot + 8 + 4 * TS + p * HDR_TABLE;
