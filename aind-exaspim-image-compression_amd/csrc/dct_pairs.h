@@ -215,6 +215,43 @@ __device__ __forceinline__ void load8p(const f2* p, f2 (&v)[8]) {
 }
 
 
+// ---- half-size transpose buffer ------------------------------------------------------------------------
+// One COMPONENT of the pair at a time through an [8][8][8] FLOAT buffer (strides below): the .x
+// values are written and read back transposed, then the .y values through the same words -- LDS
+// executes a wave's instructions in order, so the second component's writes cannot overtake the first
+// one's reads and no wait separates them.  Half the LDS per wave (the hard-threshold kernel trades it
+// for ring planes, stage_kernels.hip) for eight more write instructions per transposition.
+// Strides in floats: TJ1 = 8 keeps the b128 reads 16-byte aligned and the [r][lo][hi] writes
+// conflict-free; TI1 = 76 (4 mod 8) makes the reads of the two hi values of a 16-lane pass fall into
+// different banks (the [hi][r][lo] writes are then two-way conflicted: 4 hi + lo).
+constexpr int TI1 = 76, TJ1 = 8;
+constexpr int TBUF1 = 640;                // floats per wave: 7 * 76 + 7 * 8 + 8 = 596 for the transposes,
+                                          // 5 * 64 float2 for the half groups' exchange
+// WB: write index r * TI1 + lo * TJ1 + hi (else hi * TI1 + r * TJ1 + lo); read 8 floats at hi * TI1 + lo * TJ1
+template <bool WB>
+__device__ __forceinline__ void transpose_half(float* tf, int hi, int lo, f2 (&v)[8]) {
+    f4 q[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            tf[WB ? r * TI1 + lo * TJ1 + hi : hi * TI1 + r * TJ1 + lo] = c ? v[r].y : v[r].x;
+        cbar();
+        const f4* src = reinterpret_cast<const f4*>(tf + hi * TI1 + lo * TJ1);
+        q[c][0] = src[0];
+        q[c][1] = src[1];
+        cbar();
+    }
+    v[0] = mk2(q[0][0].x, q[1][0].x);
+    v[1] = mk2(q[0][0].y, q[1][0].y);
+    v[2] = mk2(q[0][0].z, q[1][0].z);
+    v[3] = mk2(q[0][0].w, q[1][0].w);
+    v[4] = mk2(q[0][1].x, q[1][1].x);
+    v[5] = mk2(q[0][1].y, q[1][1].y);
+    v[6] = mk2(q[0][1].z, q[1][1].z);
+    v[7] = mk2(q[0][1].w, q[1][1].w);
+}
+
 // ---- lo <-> register transposition without LDS ----------------------------------------------------
 // Within every group of 8 lanes (same hi), lane a / register b holds X[a][b] before and X[b][a]
 // after: three butterfly stages over the index bits 4, 2, 1, each swapping X[l][r] with
@@ -270,9 +307,17 @@ __device__ __forceinline__ void transpose_lo(f2 (&v)[8], int lo) {
 
 // 3-D DCT of TWO blocks at once (streams .x / .y; the transpose buffer holds float2 elements).
 // In: layout L1, out: L3.
-template <typename TableT>
+template <bool HALF = false, typename TableT>
 __device__ __forceinline__ void pair_fwd(const TableT& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_fwd2(T, v);                                             // along y
+    if constexpr (HALF) {
+        float* tf = reinterpret_cast<float*>(tb);
+        transpose_half<false>(tf, hi, lo, v);                    // L2: hi = z, lo = y, regs x
+        dct8_fwd2(T, v);                                         // along x
+        transpose_half<true>(tf, hi, lo, v);                     // L3: hi = x, lo = y, regs z
+        dct8_fwd2(T, v);                                         // along z
+        return;
+    }
 #if EXABM4D_DPP_TR
     transpose_lo(v, lo);                                         // L2: hi = z, lo = y, regs x
 #else
@@ -295,8 +340,22 @@ __device__ __forceinline__ void pair_fwd(const TableT& T, f2* tb, int hi, int lo
 // its way back from LDS, pair B's arithmetic runs, and vice versa.  LDS executes a wave's
 // instructions in issue order, so B's writes (issued after A's reads) cannot overtake them and
 // one buffer serves both; the compiler fences only pin the order of the LDS accesses.
-template <typename TableT>
+template <bool HALF = false, typename TableT>
 __device__ __forceinline__ void pair_fwd_x2(const TableT& T, f2* tb, int hi, int lo, f2 (&a)[8], f2 (&b)[8]) {
+    if constexpr (HALF) {
+        float* tf = reinterpret_cast<float*>(tb);
+        dct8_fwd2(T, a);                                         // A along y
+        transpose_half<false>(tf, hi, lo, a);                    // (in flight)
+        dct8_fwd2(T, b);                                         // B along y
+        transpose_half<false>(tf, hi, lo, b);
+        dct8_fwd2(T, a);                                         // A along x
+        transpose_half<true>(tf, hi, lo, a);
+        dct8_fwd2(T, b);                                         // B along x
+        transpose_half<true>(tf, hi, lo, b);
+        dct8_fwd2(T, a);                                         // A along z
+        dct8_fwd2(T, b);                                         // B along z
+        return;
+    }
     dct8_fwd2(T, a);                                             // A along y
 #pragma unroll
     for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = a[y];
@@ -324,8 +383,22 @@ __device__ __forceinline__ void pair_fwd_x2(const TableT& T, f2* tb, int hi, int
     dct8_fwd2(T, a);                                             // A along z
     dct8_fwd2(T, b);                                             // B along z
 }
-template <typename TableT>
+template <bool HALF = false, typename TableT>
 __device__ __forceinline__ void pair_inv_x2(const TableT& T, f2* tb, int hi, int lo, f2 (&a)[8], f2 (&b)[8]) {
+    if constexpr (HALF) {
+        float* tf = reinterpret_cast<float*>(tb);
+        dct8_inv2(T, a);                                         // A along z
+        transpose_half<true>(tf, hi, lo, a);
+        dct8_inv2(T, b);                                         // B along z
+        transpose_half<true>(tf, hi, lo, b);
+        dct8_inv2(T, a);                                         // A along x
+        transpose_half<false>(tf, hi, lo, a);
+        dct8_inv2(T, b);                                         // B along x
+        transpose_half<false>(tf, hi, lo, b);
+        dct8_inv2(T, a);                                         // A along y
+        dct8_inv2(T, b);                                         // B along y
+        return;
+    }
     dct8_inv2(T, a);                                             // A along z
 #pragma unroll
     for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = a[z];
@@ -355,9 +428,17 @@ __device__ __forceinline__ void pair_inv_x2(const TableT& T, f2* tb, int hi, int
 }
 
 // Inverse of pair_fwd: L3 spectra in, spatial blocks in layout L1 out.
-template <typename TableT>
+template <bool HALF = false, typename TableT>
 __device__ __forceinline__ void pair_inv(const TableT& T, f2* tb, int hi, int lo, f2 (&v)[8]) {
     dct8_inv2(T, v);                                             // along z (L3: hi = x, lo = y)
+    if constexpr (HALF) {
+        float* tf = reinterpret_cast<float*>(tb);
+        transpose_half<true>(tf, hi, lo, v);                     // L2: hi = z, lo = y, regs x
+        dct8_inv2(T, v);                                         // along x
+        transpose_half<false>(tf, hi, lo, v);                    // L1: hi = z, lo = x, regs y
+        dct8_inv2(T, v);                                         // along y
+        return;
+    }
 #pragma unroll
     for (int z = 0; z < 8; z++) tb[z * TSI + lo * TSJ + hi] = v[z];  // buffer [z][y][x]
     cbar();

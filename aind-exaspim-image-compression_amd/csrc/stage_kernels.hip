@@ -678,6 +678,9 @@ __device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLa
 #ifndef EXABM4D_HT_NPL
 #define EXABM4D_HT_NPL 18
 #endif
+#ifndef EXABM4D_HT_HALF_TBUF
+#define EXABM4D_HT_HALF_TBUF 0                 // 1: half-size transpose buffers (dct_pairs.h) -> more ring planes
+#endif
 #ifndef EXABM4D_WIE_NW
 #define EXABM4D_WIE_NW 8
 #endif
@@ -690,8 +693,10 @@ __device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLa
 #ifndef EXABM4D_WIE_NPL
 #define EXABM4D_WIE_NPL 22
 #endif
-template <int NW_, int TY_, int TX_, int NPL_>
+template <int NW_, int TY_, int TX_, int NPL_, bool HALFTB_ = false>
 struct HalfGeom {
+    static constexpr bool HALFTB = HALFTB_;             // one pair component at a time through a float buffer
+    static constexpr int TBW = HALFTB_ ? TBUF1 : 2 * TBUF;   // floats of LDS per wave buffer
     static constexpr int NW = NW_;                      // waves: pair p = wave >> 1, half h = wave & 1 (the
                                                         // waves of a pair sit on different SIMDs)
     static constexpr int TY = TY_, TX = TX_;            // grid points per tile in y and x
@@ -700,12 +705,12 @@ struct HalfGeom {
     static constexpr int PS = ((ROWS * COLS + 23) / 32) * 32 + 8;  // plane stride in elements, 8 (mod 32)
     static constexpr int NPL = NPL_;                    // ring planes: 18 live ones + slack for running
                                                         // ahead of the flush (per-block gate below)
-    static constexpr size_t LDS_FLOATS = (size_t)2 * NPL * PS + (size_t)NW * 2 * TBUF + 4 + 2 * NW + 8;
+    static constexpr size_t LDS_FLOATS = (size_t)2 * NPL * PS + (size_t)NW * TBW + 4 + 2 * NW + 8;
     static_assert(NW % 2 == 0 && NW <= 16 && NPL >= 18 && NPL <= 26, "pairs of waves; at most 3 layers in flight");
     static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "ring + transpose buffers exceed the CU's LDS");
 };
 template <bool WIENER>
-struct HalfCfg : HalfGeom<EXABM4D_HT_NW, EXABM4D_HT_TY, EXABM4D_HT_TX, EXABM4D_HT_NPL> {};
+struct HalfCfg : HalfGeom<EXABM4D_HT_NW, EXABM4D_HT_TY, EXABM4D_HT_TX, EXABM4D_HT_NPL, EXABM4D_HT_HALF_TBUF != 0> {};
 template <>
 struct HalfCfg<true> : HalfGeom<EXABM4D_WIE_NW, EXABM4D_WIE_TY, EXABM4D_WIE_TX, EXABM4D_WIE_NPL> {};
 constexpr int HNCNT = 8;                      // per-layer report counters
@@ -976,7 +981,7 @@ __device__ __forceinline__ bool process_half_group(
                     gather8v(noisy_r, corner_of(kb + kl + 6), voff, c);
                     gather8v(noisy_r, corner_of(kb + kl + 7), voff, d);
                 }
-                pair_fwd_x2(T, tb, hi, lo, v2, w2);
+                pair_fwd_x2<C::HALFTB>(T, tb, hi, lo, v2, w2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -996,7 +1001,7 @@ __device__ __forceinline__ bool process_half_group(
                     gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
                     gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
                 }
-                pair_fwd(T, tb, hi, lo, v2);
+                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
                 if constexpr (KH > 1) {
@@ -1010,7 +1015,7 @@ __device__ __forceinline__ bool process_half_group(
             gather8v(basic_r, c0, voff, b);
 #pragma unroll
             for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-            pair_fwd(T, tb, hi, lo, v2);
+            pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 S[j >> 1][j & 1] = v2[j].x;
@@ -1025,7 +1030,7 @@ __device__ __forceinline__ bool process_half_group(
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
                 gather8v(basic_r, corner_of(kb + kl), voff, a);
                 gather8v(basic_r, corner_of(kb + kl + 1), voff, b);
-                pair_fwd(T, tb, hi, lo, v2);
+                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -1037,7 +1042,7 @@ __device__ __forceinline__ bool process_half_group(
                     gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
                     gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
                 }
-                pair_fwd(T, tb, hi, lo, v2);
+                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     SB[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -1217,7 +1222,7 @@ __device__ __forceinline__ bool process_half_group(
                     v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl + 2 + (j & 1)]);
                     w2[j] = mk2(S[j >> 1][2 * kl + 4 + (j & 1)], S[j >> 1][2 * kl + 6 + (j & 1)]);
                 }
-                pair_inv_x2(T, tb, hi, lo, v2, w2);
+                pair_inv_x2<C::HALFTB>(T, tb, hi, lo, v2, w2);
                 STAMP(tl1);
                 gate(kb + kl);
                 ring_add(ring_off(kb + kl), v2, 0);
@@ -1238,7 +1243,7 @@ __device__ __forceinline__ bool process_half_group(
 #pragma unroll
                 for (int j = 0; j < 8; j++)
                     v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
-                pair_inv(T, tb, hi, lo, v2);
+                pair_inv<C::HALFTB>(T, tb, hi, lo, v2);
                 STAMP(tl1);
                 gate(kb + kl);
                 ring_add(ring_off(kb + kl), v2, 0);
@@ -1295,9 +1300,9 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     ring_t* ring = reinterpret_cast<ring_t*>(lds);         // [HNPL][HPS] numerator sums (fp64)
     // readfirstlane: the wave index steers register indexing below and must be provably uniform
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * 2 * TBUF);
-    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + (wave ^ 1) * 2 * TBUF);
-    int* lock = reinterpret_cast<int*>(lds + 2 * HNPL * HPS + HNW * 2 * TBUF);
+    f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * C::TBW);
+    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + (wave ^ 1) * C::TBW);
+    int* lock = reinterpret_cast<int*>(lds + 2 * HNPL * HPS + HNW * C::TBW);
     int* sync = lock + 4;                                  // ready[HNW], ack[HNW]
     int* cnt = sync + 2 * HNW;                             // reports per layer (slot = layer & 7)
 
