@@ -1,6 +1,6 @@
 // dct_pairs.h -- the 8x8x8 separable DCT of TWO blocks at once as packed-fp32 streams, shared by
 // the collaborative-filtering kernels (stage_kernels.hip) and the transform quantiser
-// (codec_kernels.hip).  Arithmetic: DESIGN.md 3.5 (even/odd-folded 4-term fmaf chains, axis order
+// (codec_kernels.hip).  Arithmetic: DESIGN.md 3.5 (even/odd fold, the even half folded once more, fmaf chains, axis order
 // y, x, z forward and z, x, y inverse), bit-identical to the oracle.
 #pragma once
 #include "exabm4d_common.h"
@@ -37,6 +37,7 @@ __device__ __forceinline__ f2 chain4p(float c0, f2 v0, float c1, f2 v1, float c2
     t = __builtin_elementwise_fma((f2)(c3), v3, t);
     return t;
 }
+// (the even half is folded a second time -- two-term outputs instead of four-term chains)
 __device__ __forceinline__ void dct8_fwd2(const DctTable& T, f2 (&v)[8]) {
     f2 s[4], d[4], o[8];
 #pragma unroll
@@ -44,25 +45,33 @@ __device__ __forceinline__ void dct8_fwd2(const DctTable& T, f2 (&v)[8]) {
         s[n] = v[n] + v[7 - n];
         d[n] = v[n] - v[7 - n];
     }
+    const float c = T.d[0], a = T.d[2 * 8 + 0], b = T.d[2 * 8 + 1];
+    const f2 ss0 = s[0] + s[3], ss1 = s[1] + s[2], sd0 = s[0] - s[3], sd1 = s[1] - s[2];
+    o[0] = (ss0 + ss1) * c;
+    o[4] = (ss0 - ss1) * c;
+    o[2] = __builtin_elementwise_fma((f2)(b), sd1, sd0 * a);
+    o[6] = __builtin_elementwise_fma((f2)(a), -sd1, sd0 * b);
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const float* c = T.d + u * 8;
-        o[u] = (u & 1) ? chain4p(c[0], d[0], c[1], d[1], c[2], d[2], c[3], d[3])
-                       : chain4p(c[0], s[0], c[1], s[1], c[2], s[2], c[3], s[3]);
+    for (int u = 1; u < 8; u += 2) {
+        const float* k = T.d + u * 8;
+        o[u] = chain4p(k[0], d[0], k[1], d[1], k[2], d[2], k[3], d[3]);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) v[u] = o[u];
 }
 __device__ __forceinline__ void dct8_inv2(const DctTable& T, f2 (&v)[8]) {
     f2 x[8];
+    const float c = T.d[0], a = T.d[2 * 8 + 0], b = T.d[2 * 8 + 1];
+    const f2 p0 = (v[0] + v[4]) * c, p1 = (v[0] - v[4]) * c;
+    const f2 q0 = __builtin_elementwise_fma((f2)(b), v[6], v[2] * a);
+    const f2 q1 = __builtin_elementwise_fma((f2)(a), -v[6], v[2] * b);
+    const f2 e[4] = {p0 + q0, p1 + q1, p1 - q1, p0 - q0};
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        const f2 e = chain4p(T.d[0 * 8 + n], v[0], T.d[2 * 8 + n], v[2], T.d[4 * 8 + n], v[4],
-                             T.d[6 * 8 + n], v[6]);
         const f2 o = chain4p(T.d[1 * 8 + n], v[1], T.d[3 * 8 + n], v[3], T.d[5 * 8 + n], v[5],
                              T.d[7 * 8 + n], v[7]);
-        x[n] = e + o;
-        x[7 - n] = e - o;
+        x[n] = e[n] + o;
+        x[7 - n] = e[n] - o;
     }
 #pragma unroll
     for (int n = 0; n < 8; n++) v[n] = x[n];
@@ -102,10 +111,11 @@ __device__ __forceinline__ void dct8_fwd2(const Dct7& q, f2 (&v)[8]) {
         s[n] = v[n] + v[7 - n];
         d[n] = v[n] - v[7 - n];
     }
-    o[0] = chain4p(q.c, s[0], q.c, s[1], q.c, s[2], q.c, s[3]);
-    o[2] = chain4p(q.a, s[0], q.b, s[1], q.b, -s[2], q.a, -s[3]);
-    o[4] = chain4p(q.c, s[0], q.c, -s[1], q.c, -s[2], q.c, s[3]);
-    o[6] = chain4p(q.b, s[0], q.a, -s[1], q.a, s[2], q.b, -s[3]);
+    const f2 ss0 = s[0] + s[3], ss1 = s[1] + s[2], sd0 = s[0] - s[3], sd1 = s[1] - s[2];
+    o[0] = (ss0 + ss1) * q.c;
+    o[4] = (ss0 - ss1) * q.c;
+    o[2] = __builtin_elementwise_fma((f2)(q.b), sd1, sd0 * q.a);
+    o[6] = __builtin_elementwise_fma((f2)(q.a), -sd1, sd0 * q.b);
     o[1] = chain4p(q.e, d[0], q.f, d[1], q.g, d[2], q.h, d[3]);
     o[3] = chain4p(q.f, d[0], q.h, -d[1], q.e, -d[2], q.g, -d[3]);
     o[5] = chain4p(q.g, d[0], q.e, -d[1], q.h, d[2], q.f, d[3]);
@@ -114,11 +124,11 @@ __device__ __forceinline__ void dct8_fwd2(const Dct7& q, f2 (&v)[8]) {
     for (int u = 0; u < 8; u++) v[u] = o[u];
 }
 __device__ __forceinline__ void dct8_inv2(const Dct7& q, f2 (&v)[8]) {
-    f2 ev[4], od[4];
-    ev[0] = chain4p(q.c, v[0], q.a, v[2], q.c, v[4], q.b, v[6]);
-    ev[1] = chain4p(q.c, v[0], q.b, v[2], q.c, -v[4], q.a, -v[6]);
-    ev[2] = chain4p(q.c, v[0], q.b, -v[2], q.c, -v[4], q.a, v[6]);
-    ev[3] = chain4p(q.c, v[0], q.a, -v[2], q.c, v[4], q.b, -v[6]);
+    f2 od[4];
+    const f2 p0 = (v[0] + v[4]) * q.c, p1 = (v[0] - v[4]) * q.c;
+    const f2 q0 = __builtin_elementwise_fma((f2)(q.b), v[6], v[2] * q.a);
+    const f2 q1 = __builtin_elementwise_fma((f2)(q.a), -v[6], v[2] * q.b);
+    const f2 ev[4] = {p0 + q0, p1 + q1, p1 - q1, p0 - q0};
     od[0] = chain4p(q.e, v[1], q.f, v[3], q.g, v[5], q.h, v[7]);
     od[1] = chain4p(q.f, v[1], q.h, -v[3], q.e, -v[5], q.g, -v[7]);
     od[2] = chain4p(q.g, v[1], q.e, -v[3], q.h, v[5], q.f, v[7]);
@@ -130,74 +140,10 @@ __device__ __forceinline__ void dct8_inv2(const Dct7& q, f2 (&v)[8]) {
     }
 }
 
-// ---- the same 8-point transforms on the matrix pipe ------------------------------------------------
-// v_mfma_f32_4x4x1_16b_f32 does 16 independent 4x4 outer products: lane l = 4 b + r supplies
-// A_b[r] and B_b[r], register i of lane l accumulates D_b[i][r] += A_b[i] * B_b[r] with ONE fp32
-// fma (CDNA4 f32-input MFMA is bit-for-bit a k-ordered fmaf chain).  With A = row (l & 3) of a 4x4
-// coefficient block and B = the lane's own folded sample, four chained instructions leave the
-// four even (or odd) outputs of the lane's OWN line in the lane's registers: the chain
-// c0*s0 -> fma(c1,s1,.) -> fma(c2,s2,.) -> fma(c3,s3,.) of chain4p, no data movement, and the
-// VALU only does the fold / unfold additions.  (fma(c0, s0, +0) instead of the product c0 * s0
-// differs only in the sign of an exact zero.)
-typedef float f4v __attribute__((ext_vector_type(4)));
-struct DctLane {
-    float fe[4], fo[4], ie[4], io[4];   // per-lane A operands: forward even / odd, inverse even / odd
-};
-__device__ __forceinline__ DctLane make_dct_lane(const DctTable& T, int lane) {
-    DctLane L;
-    const int i = lane & 3;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        // selects instead of a lane-indexed read: T lives in scalar registers / kernel arguments
-        auto pick = [&](float a, float b, float c, float d) {
-            return i == 0 ? a : i == 1 ? b : i == 2 ? c : d;
-        };
-        L.fe[k] = pick(T.d[0 * 8 + k], T.d[2 * 8 + k], T.d[4 * 8 + k], T.d[6 * 8 + k]);
-        L.fo[k] = pick(T.d[1 * 8 + k], T.d[3 * 8 + k], T.d[5 * 8 + k], T.d[7 * 8 + k]);
-        L.ie[k] = pick(T.d[(2 * k) * 8 + 0], T.d[(2 * k) * 8 + 1], T.d[(2 * k) * 8 + 2],
-                       T.d[(2 * k) * 8 + 3]);
-        L.io[k] = pick(T.d[(2 * k + 1) * 8 + 0], T.d[(2 * k + 1) * 8 + 1], T.d[(2 * k + 1) * 8 + 2],
-                       T.d[(2 * k + 1) * 8 + 3]);
-    }
-    return L;
-}
-__device__ __forceinline__ void dct8_fwd2(const DctLane& L, f2 (&v)[8]) {
-    f2 s[4], d[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        s[n] = v[n] + v[7 - n];
-        d[n] = v[n] - v[7 - n];
-    }
-    f4v ex = (f4v)(0.0f), ox = (f4v)(0.0f), ey = (f4v)(0.0f), oy = (f4v)(0.0f);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        ex = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fe[k], s[k].x, ex, 0, 0, 0);
-        ox = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fo[k], d[k].x, ox, 0, 0, 0);
-        ey = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fe[k], s[k].y, ey, 0, 0, 0);
-        oy = __builtin_amdgcn_mfma_f32_4x4x1f32(L.fo[k], d[k].y, oy, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        v[2 * i] = mk2(ex[i], ey[i]);
-        v[2 * i + 1] = mk2(ox[i], oy[i]);
-    }
-}
-__device__ __forceinline__ void dct8_inv2(const DctLane& L, f2 (&v)[8]) {
-    f4v ex = (f4v)(0.0f), ox = (f4v)(0.0f), ey = (f4v)(0.0f), oy = (f4v)(0.0f);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        ex = __builtin_amdgcn_mfma_f32_4x4x1f32(L.ie[k], v[2 * k].x, ex, 0, 0, 0);
-        ox = __builtin_amdgcn_mfma_f32_4x4x1f32(L.io[k], v[2 * k + 1].x, ox, 0, 0, 0);
-        ey = __builtin_amdgcn_mfma_f32_4x4x1f32(L.ie[k], v[2 * k].y, ey, 0, 0, 0);
-        oy = __builtin_amdgcn_mfma_f32_4x4x1f32(L.io[k], v[2 * k + 1].y, oy, 0, 0, 0);
-    }
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        const f2 e = mk2(ex[n], ey[n]), o = mk2(ox[n], oy[n]);
-        v[n] = e + o;
-        v[7 - n] = e - o;
-    }
-}
+// (Round 1 also carried the transforms on the matrix pipe -- v_mfma_f32_4x4x1_16b_f32, whose chained
+// accumulation is bit-for-bit the four-term fmaf chain; 3 % / 11 % slower than the packed VALU form.
+// That option ended with the four-term even outputs it reproduced: tools/dbg/mfma4x4_probe.hip keeps
+// the operand-layout probe.)
 
 // The transpose buffer is private to one wave and LDS executes a wave's instructions in issue
 // order, so between its writes and its (cross-lane) reads only the COMPILER must be kept from

@@ -51,45 +51,6 @@ constexpr int PS = 904;                   // ring plane stride: 900 padded to 8 
 constexpr int NPL = 18;                   // ring planes: z0-5 .. z0+12
 constexpr float HAAR_C = 0.70710678118654752440f;
 
-__device__ __forceinline__ float chain4(float c0, float v0, float c1, float v1, float c2, float v2,
-                                        float c3, float v3) {
-    float t = c0 * v0;
-    t = fmaf(c1, v1, t);
-    t = fmaf(c2, v2, t);
-    t = fmaf(c3, v3, t);
-    return t;
-}
-__device__ __forceinline__ void dct8_fwd(const DctTable& T, float (&v)[8]) {
-    float s[4], d[4], o[8];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        s[n] = v[n] + v[7 - n];
-        d[n] = v[n] - v[7 - n];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const float* c = T.d + u * 8;
-        o[u] = (u & 1) ? chain4(c[0], d[0], c[1], d[1], c[2], d[2], c[3], d[3])
-                       : chain4(c[0], s[0], c[1], s[1], c[2], s[2], c[3], s[3]);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = o[u];
-}
-__device__ __forceinline__ void dct8_inv(const DctTable& T, float (&v)[8]) {
-    float x[8];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        const float e = chain4(T.d[0 * 8 + n], v[0], T.d[2 * 8 + n], v[2], T.d[4 * 8 + n], v[4],
-                               T.d[6 * 8 + n], v[6]);
-        const float o = chain4(T.d[1 * 8 + n], v[1], T.d[3 * 8 + n], v[3], T.d[5 * 8 + n], v[5],
-                               T.d[7 * 8 + n], v[7]);
-        x[n] = e + o;
-        x[7 - n] = e - o;
-    }
-#pragma unroll
-    for (int n = 0; n < 8; n++) v[n] = x[n];
-}
-
 // Orthonormal Haar along the group axis on the first K elements of a <16 x float>.
 template <int K>
 __device__ __forceinline__ void haar_fwd(f16v& v) {
@@ -646,16 +607,6 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
 #ifndef EXABM4D_PRIO
 #define EXABM4D_PRIO 1                         // 0: no wave priorities (A/B builds)
 #endif
-#ifndef EXABM4D_MFMA_DCT
-#define EXABM4D_MFMA_DCT 0                     // 0: VALU chains (default: faster), 1: hard-threshold kernel on MFMA, 2: both kernels
-#endif
-template <bool M>
-__device__ __forceinline__ const auto& pick_table(const DctTable& T, const DctLane& L) {
-    if constexpr (M)
-        return L;
-    else
-        return T;
-}
 #ifndef EXABM4D_X2
 #define EXABM4D_X2 1                           // 0: one block pair per transform everywhere (A/B builds)
 #endif
@@ -1283,11 +1234,7 @@ __device__ __forceinline__ bool process_half_group(
     return __builtin_amdgcn_readfirstlane(closer) != 0;
 }
 
-#if EXABM4D_MFMA_DCT
-typedef DctTable HalfTable;
-#else
 typedef Dct7 HalfTable;       // seven scalars instead of a 64-entry table in SGPRs (dct_pairs.h)
-#endif
 template <bool WIENER>
 __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
@@ -1342,14 +1289,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const int pairid = wave >> 1;
     int seq = 0;
     int seen = 0;           // last value read of lock[1] (layers retired), see the per-block gate
-    // 8-point transforms on the matrix pipe (dct_pairs.h) where the registers allow it
-#if EXABM4D_MFMA_DCT
-    constexpr bool ON_MFMA = WIENER ? (EXABM4D_MFMA_DCT >= 2) : (EXABM4D_MFMA_DCT >= 1);
-    const DctLane TL = ON_MFMA ? make_dct_lane(T, lane) : DctLane{};
-    const auto& tab = pick_table<ON_MFMA>(T, TL);
-#else
     const Dct7& tab = T;
-#endif
 #ifdef EXABM4D_STAMPS
     unsigned long long st[16] = {};
     const unsigned long long tk0 = stamp();
@@ -1468,12 +1408,8 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         const size_t n = (size_t)g.nvox * (size_t)batch;
         hipError_t e = hipMemsetAsync(cwork, 0, n * sizeof(float), stream);
         if (e != hipSuccess) return e;
-#if EXABM4D_MFMA_DCT
-        const DctTable& HT = T;
-#else
         Dct7 HT;
         if (!make_dct7(T, HT)) return hipErrorInvalidValue;    // the table lost its symmetry
-#endif
         auto launch = [&](auto wiener_c) -> hipError_t {
             constexpr bool W = decltype(wiener_c)::value;
             using C = HalfCfg<W>;

@@ -201,6 +201,7 @@ void cpu_blockmatch(const float* vol, int nz, int ny, int nx, float sigma, float
 #define HAAR_C 0.70710678118654752440f
 /* 8-point DCT along an axis of element stride `es` for `nl` lines that are contiguous in memory */
 static inline void dct_lines_fwd(const float* D, float* v, size_t es, int nl) {
+    const float c = D[0], a = D[2 * 8 + 0], b = D[2 * 8 + 1];
 #pragma omp simd
     for (int l = 0; l < nl; l++) {
         float s[4], d[4], o[8];
@@ -208,34 +209,38 @@ static inline void dct_lines_fwd(const float* D, float* v, size_t es, int nl) {
             s[n] = v[n * es + l] + v[(7 - n) * es + l];
             d[n] = v[n * es + l] - v[(7 - n) * es + l];
         }
-        for (int u = 0; u < 8; u++) {
-            const float* c = D + u * 8;
-            const float* w = (u & 1) ? d : s;
-            float t = c[0] * w[0];
-            t = fmaf(c[1], w[1], t);
-            t = fmaf(c[2], w[2], t);
-            t = fmaf(c[3], w[3], t);
+        const float ss0 = s[0] + s[3], ss1 = s[1] + s[2], sd0 = s[0] - s[3], sd1 = s[1] - s[2];
+        o[0] = c * (ss0 + ss1);
+        o[4] = c * (ss0 - ss1);
+        o[2] = fmaf(b, sd1, a * sd0);
+        o[6] = fmaf(-a, sd1, b * sd0);
+        for (int u = 1; u < 8; u += 2) {
+            const float* k = D + u * 8;
+            float t = k[0] * d[0];
+            t = fmaf(k[1], d[1], t);
+            t = fmaf(k[2], d[2], t);
+            t = fmaf(k[3], d[3], t);
             o[u] = t;
         }
         for (int u = 0; u < 8; u++) v[u * es + l] = o[u];
     }
 }
 static inline void dct_lines_inv(const float* D, float* v, size_t es, int nl) {
+    const float c = D[0], a = D[2 * 8 + 0], b = D[2 * 8 + 1];
 #pragma omp simd
     for (int l = 0; l < nl; l++) {
-        float c[8], x[8];
-        for (int u = 0; u < 8; u++) c[u] = v[u * es + l];
+        float k[8], x[8];
+        for (int u = 0; u < 8; u++) k[u] = v[u * es + l];
+        const float p0 = c * (k[0] + k[4]), p1 = c * (k[0] - k[4]);
+        const float q0 = fmaf(b, k[6], a * k[2]), q1 = fmaf(-a, k[6], b * k[2]);
+        const float e[4] = {p0 + q0, p1 + q1, p1 - q1, p0 - q0};
         for (int n = 0; n < 4; n++) {
-            float e = D[0 * 8 + n] * c[0];
-            e = fmaf(D[2 * 8 + n], c[2], e);
-            e = fmaf(D[4 * 8 + n], c[4], e);
-            e = fmaf(D[6 * 8 + n], c[6], e);
-            float o = D[1 * 8 + n] * c[1];
-            o = fmaf(D[3 * 8 + n], c[3], o);
-            o = fmaf(D[5 * 8 + n], c[5], o);
-            o = fmaf(D[7 * 8 + n], c[7], o);
-            x[n] = e + o;
-            x[7 - n] = e - o;
+            float o = D[1 * 8 + n] * k[1];
+            o = fmaf(D[3 * 8 + n], k[3], o);
+            o = fmaf(D[5 * 8 + n], k[5], o);
+            o = fmaf(D[7 * 8 + n], k[7], o);
+            x[n] = e[n] + o;
+            x[7 - n] = e[n] - o;
         }
         for (int n = 0; n < 8; n++) v[n * es + l] = x[n];
     }
