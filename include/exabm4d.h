@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXABM4D_VERSION 100 /* 0.1.0 */
+#define EXABM4D_VERSION 200 /* 0.2.0: + chunk coder, chunk-local mode, staged uint16 entry points (round 2) */
 
 typedef enum exabm4d_status {
     EXABM4D_OK = 0,
