@@ -6,7 +6,9 @@ created lazily, *after* any ``fork()`` -- the reference calls ``bm4d`` from fork
 ``ProcessPoolExecutor`` workers (reference ``scripts/precompute.py:215``).
 """
 import ctypes
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -152,12 +154,58 @@ def library_path():
         "CPU fallback for the HIP hot path." % [p for p in _LIB_CANDIDATES if p])
 
 
+def _mapped_hip_runtimes():
+    """Real paths of every libamdhip64 image mapped into this process (/proc/self/maps)."""
+    seen = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    seen.add(os.path.realpath(line.split(None, 5)[-1].strip()))
+    except OSError:
+        pass
+    return seen
+
+
+def _adopt_torch_hip_runtime():
+    """PyTorch-ROCm wheels carry their own libamdhip64.so (same SONAME as /opt/rocm's).  Two copies
+    in one process leave the one loaded second without devices, whichever side it belongs to: the
+    reference's callers import ``bm4d`` first and torch later (data_handling.py:12, inference.py),
+    so the order is not ours to choose.  Rule: when a torch with a bundled HIP runtime is
+    installed, ITS runtime is the process's runtime -- it is mapped here (dlopen only: no HIP
+    call, no device initialisation, torch itself is not imported) before libexabm4d.so, whose
+    DT_NEEDED ``libamdhip64.so.7`` then binds to the image already loaded under that SONAME.
+    ``EXABM4D_SYSTEM_HIP=1`` keeps /opt/rocm's runtime (for processes that never load torch)."""
+    if os.environ.get("EXABM4D_SYSTEM_HIP") == "1":
+        return None
+    if _mapped_hip_runtimes():
+        return None                       # somebody (torch, rocprofv3, the caller) already chose
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    return path
+
+
 def lib():
     """Load the shared library (no GPU needed for this) and bind every symbol."""
     global _lib
     with _lib_lock:
         if _lib is None:
+            _adopt_torch_hip_runtime()
             L = ctypes.CDLL(library_path())
+            mapped = _mapped_hip_runtimes()
+            if len(mapped) > 1:
+                raise NativeError(
+                    "two HIP runtimes are mapped into this process (%s): the one loaded second has "
+                    "no devices.  Load libexabm4d.so and torch against the same libamdhip64 "
+                    "(see INTEGRATION.md 1d)." % ", ".join(sorted(mapped)))
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
                 fn.restype = res
@@ -547,7 +595,13 @@ def context(device=None):
 
 
 def device_count():
-    return int(lib().exabm4d_device_count())
+    """Number of visible devices.  hipGetDeviceCount initialises the HIP runtime, so the calling
+    process counts as a HIP owner for the fork guard from here on."""
+    global _hip_owner_pid
+    n = int(lib().exabm4d_device_count())
+    if _hip_owner_pid is None:
+        _hip_owner_pid = os.getpid()
+    return n
 
 
 # -- host-only helpers (no GPU) -----------------------------------------------------------------

@@ -258,12 +258,16 @@ def torch_encode_legs(ctx, own, dev):
     sz32 = torch.empty(nchunks_i, dtype=torch.int32, device=dev)
 
     def encode(out):
+        # `out` was produced on torch's current stream (a torch.cat / .contiguous() copy is
+        # asynchronous): the coder runs on that stream too, not on the context's private one
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         ctx.codec_encode(out, 2, own, CHUNK, out=enc16, out_capacity=cap16, offsets=off16,
                          sizes=sz16, totals=False)
         ctx.dctq_forward(out, own, Q_STEP, idx)
         ctx.codec_encode(idx, 4, idx_shape, idx_chunk, out=enc32, out_capacity=cap32,
                          offsets=off32, sizes=sz32, totals=False)
         ctx.sync()
+        ctx.reset_stream()
 
     return encode, sz16
 
@@ -407,6 +411,45 @@ def run_chunks(args, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process starts N ranks of itself -- one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the rendezvous on
+    127.0.0.1 -- waits for them and exits with the first non-zero status.  It runs before anything
+    here has touched the GPU (no torch, no libexabm4d.so in the parent): children are fresh
+    processes, the independent-worker shape of the reference's scripts/precompute.py:215-228."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:            # a dead rank leaves the others in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,11 +473,17 @@ def main():
                     help="edge of the sub-volume of the BM4DNet (config 3) leg, reported as extra keys; 0 disables")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))     # every mode: volumes, slabs, chunks
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if os.environ.get("BENCH_FAIL_RANK") == str(rank) and world > 1:
+        raise SystemExit(3)                     # tests: a rank that dies must fail the launcher
 
     dist = None
     torch = None
@@ -451,11 +500,10 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    if args.bm4dnet > 0 and world == 1 and args.mode == "volumes":
-        # the BM4DNet leg needs torch's HIP runtime: load it BEFORE libexabm4d.so pulls in the
-        # system one (two copies of libamdhip64 in one process leave the second without devices)
-        import torch  # noqa: F401
+    # (import order of torch and libexabm4d.so is free: _native.lib() settles which HIP runtime the
+    # process uses -- INTEGRATION.md 1d)
     from aind_exaspim_image_compression import _native
 
     if args.mode == "slabs":

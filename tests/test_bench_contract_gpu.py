@@ -50,3 +50,50 @@ def test_default_line_has_the_contract_keys():
 def test_no_encode_flag_says_so():
     d = _run("--no-encode", "--cpu-sample", "0")
     assert d["config"]["encode"] == "none" and "encode_u16" not in d["phase_ms"] and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["volumes", "slabs", "chunks"])
+def test_gpus_flag_launches_its_own_ranks(mode):
+    """`python bench.py --gpus 2` with no launcher around it (how the driver calls it) must start two
+    ranks itself: n_gpus == 2 in the line and twice the voxels of one rank.  BENCH_REHEARSAL=1 puts
+    both ranks on this box's one GPU with a gloo rendezvous (never the measured configuration)."""
+    env = dict(os.environ, BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    extra = ["--mode", mode] + (["--chunk", "32"] if mode == "chunks" else [])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64",
+                          "--steps", "1", "--warmup", "1", "--bm4dnet", "0", "--cpu-sample", "0", *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 64 ** 3 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_fails_the_launcher():
+    env = dict(os.environ, BENCH_REHEARSAL="1", BENCH_FAIL_RANK="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64",
+                          "--steps", "1", "--warmup", "0", "--bm4dnet", "0", "--cpu-sample", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0
+
+
+def test_launcher_parent_never_touches_the_gpu_or_torch():
+    """CPU: the parent of `--gpus N` only spawns; with a bogus interpreter argument list the children
+    die at once and the parent reports it -- without having imported torch or libexabm4d.so."""
+    code = ("import sys, bench\n"
+            "sys.argv = ['bench.py', '--gpus', '2', '--definitely-not-a-flag']\n"
+            "rc = bench.launch_ranks(2)\n"
+            "assert rc != 0, rc\n"
+            "assert 'torch' not in sys.modules and 'aind_exaspim_image_compression._native' not in sys.modules\n"
+            "print('parent clean, rc', rc)\n")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                         env=env)
+    assert out.returncode == 0 and "parent clean" in out.stdout, out.stderr[-2000:]
