@@ -113,8 +113,10 @@ def denoise_volume(vol_u16, sigma, offset=0.0, profile=None, stages=2, device=No
 def denoise_chunked(vol_u16, sigma, offset=0.0, chunk=256, halo=8, profile=None, stages=2,
                     device=None):
     """Chunk-local mode of BASELINE.json config 4: the volume is tiled by ``chunk``^3 cores, every
-    core is read with ``halo`` voxels on each side (edge-replicated at the volume's faces) and
-    denoised in isolation -- independent units, like the reference's one-``bm4d``-call-per-patch
+    core is read with ``halo`` voxels on each side -- the read window is CUT where the volume ends,
+    nothing is padded or replicated at the faces (SURVEY.md appendix A item 11's
+    "edge clamping" is read as clamping the window, and the oracle processes the identical
+    truncated arrays) -- and denoised in isolation -- independent units, like the reference's one-``bm4d``-call-per-patch
     pool (scripts/precompute.py:215-228) -- and only the cores are written.  One batched device
     call (``exabm4d_denoise_chunked_u16_dev``); uint16 in, uint16 out."""
     vol = np.ascontiguousarray(vol_u16, dtype=np.uint16)

@@ -21,6 +21,16 @@ from dataclasses import dataclass
 EXACT_HALO = 24
 
 
+def offset_exact_in_fp32(offset):
+    """(float)v - offset is exact for every uint16 v iff the offset has at most 7 fractional bits;
+    only then does matching on the uint16 planes give the tables of matching on the fp32 counts
+    (csrc/exabm4d_api.hip: offset_exact_in_fp32)."""
+    import numpy as np
+    off = np.float32(offset)
+    s = off * np.float32(128.0)
+    return bool(abs(off) <= 65536.0 and s == np.rint(s))
+
+
 @dataclass(frozen=True)
 class SlabPlan:
     rank: int
@@ -207,7 +217,11 @@ class SlabDenoiser:
             ctx.counts_from_u16(raw, noisy, n, float(offset))
             self.num.zero_()
             self.den.zero_()
-            ctx.blockmatch_u16(raw, self.shape, self.sigma, self.params.c_match_ht, self.keys,
+            if offset_exact_in_fp32(offset):
+                ctx.blockmatch_u16(raw, self.shape, self.sigma, self.params.c_match_ht, self.keys,
+                                   self.params)
+            else:                       # (float)v - offset is rounded: match on what stage 1 filters
+                ctx.blockmatch(noisy, self.shape, self.sigma, self.params.c_match_ht, self.keys,
                                self.params)
             ctx.stage(noisy, None, self.keys, self.shape, self.sigma, self.num, self.den, self.params)
             ctx.normalize(self.num, self.den, basic, n)

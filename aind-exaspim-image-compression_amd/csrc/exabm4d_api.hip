@@ -558,6 +558,15 @@ int exabm4d_normalize_u16_dev(exabm4d_ctx* ctx, const float* num, const float* d
     return EXABM4D_OK;
 }
 
+// (float)v - offset is exact in fp32 for every uint16 v iff the offset has at most 7 fractional bits
+// (17 integer bits of |v - offset| + 7 = 24) -- 0, 37, 100.5 ...; only then do two voxels of the
+// fp32 counts differ by an exact integer and the integer matching kernel reproduce the float
+// kernel's (and the oracle's) tables.  A percentile such as 36.73 takes the float kernel.
+static bool offset_exact_in_fp32(float offset) {
+    const float s = offset * 128.0f;
+    return std::fabs(offset) <= 65536.0f && s == std::rint(s);
+}
+
 // Bracket one phase of a pipeline call with events when profiling is on.
 struct PhaseTimer {
     exabm4d_ctx* ctx;
@@ -615,6 +624,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);
         const double tau512 = (double)p->c_match_ht * (double)sigma * (double)sigma * 512.0;
         const bool use16 = noisy16 && ctx->bm_int && tau512 < 16777216.0 && (g.nx % 2) == 0 &&
+                           offset_exact_in_fp32(u16_offset) &&
                            guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
         HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
                                        ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr));
@@ -765,7 +775,7 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                     uint16_t* vol16 = reinterpret_cast<uint16_t*>(scratch + base + fbytes + GUARD_BYTES);
                     HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream, vol16));
                     rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f,
-                                      scratch, 1, vol16);
+                                      scratch, 1, offset_exact_in_fp32(offset) ? vol16 : nullptr);
                     if (rc) return rc;
                     HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
                 }

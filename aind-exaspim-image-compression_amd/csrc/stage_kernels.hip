@@ -778,7 +778,16 @@ template <class C>
 __device__ __forceinline__ bool flush_take(int* lock, ring_t* ring, float* __restrict__ num, const TileGeom& tg,
                                            const VolGeom& g, int izb, int lane) {
     int w = lane == 0 ? __hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-    if ((__builtin_amdgcn_readfirstlane(w) >> 16) == 0) return false;
+    w = __builtin_amdgcn_readfirstlane(w);
+    if ((w >> 16) == 0) return false;
+    {
+        // every plane of the open flush already drawn: do not draw again.  A wave polling here while
+        // the last takers are still flushing would otherwise keep incrementing the 16-bit index
+        // field (one void draw per poll) and, given a long enough stall, carry into the generation
+        // bits; with this check a flush sees at most one void draw per wave.
+        const int izp = izb + (w >> 16) - 1;
+        if ((w & 0xFFFF) >= grid_pos(izp + 1, g.az, g.nz) - grid_pos(izp, g.az, g.nz)) return false;
+    }
     w = lane == 0 ? __hip_atomic_fetch_add(lock + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
     w = __builtin_amdgcn_readfirstlane(w);
     const int gen = w >> 16, i = w & 0xFFFF;

@@ -359,3 +359,37 @@ def test_integer_block_matching_batch_of_patches(ctx, oracle):
     got = _keys_u16(ctx, vols, SIGMA, 3.0, batch=3)
     for i in range(3):
         np.testing.assert_array_equal(got[i], oracle.blockmatch(vols[i].astype(np.float32) - 37.0, SIGMA, 3.0))
+
+
+def test_non_dyadic_offset_takes_the_float_kernel(ctx, oracle):
+    """An offset such as 36.73 (a percentile from estimate_offset) makes (float)v - offset inexact in
+    fp32: voxel differences are no longer integers, so the integer matching kernel would not give
+    the float kernel's tables.  The launcher must fall back to the float kernel for such offsets
+    (offset * 128 not an integer): switching the integer path off changes nothing, and the result
+    is the oracle's (which always matches on the fp32 counts) within a count.  With a dyadic
+    offset the integer kernel does run, and its result is the float kernel's too."""
+    vol = synth_volume((40, 48, 64), seed=77, as_u16=True)[0]
+
+    def run(offset, bm_int):
+        ctx.set_option("bm_int", bm_int)
+        d_in, d_out = ctx.to_device(vol), ctx.alloc(vol.nbytes)
+        try:
+            ctx.denoise_u16(d_in, d_out, vol.shape, SIGMA, offset)
+            return d_out.download(vol.shape, np.uint16)
+        finally:
+            ctx.set_option("bm_int", 1)
+            d_in.free()
+            d_out.free()
+
+    for offset in (36.73, 0.3, 100.5, 37.0):
+        a, b = run(offset, 1), run(offset, 0)
+        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
+        # same tables => same groups; only the aggregation's arrival order differs between runs
+        assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (offset, int(d.max()), float(np.mean(d > 0)))
+        want = oracle.bm4d_u16(vol, SIGMA, offset)
+        d = np.abs(a.astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (offset, int(d.max()), float(np.mean(d > 0)))
+    # the gate itself, on the host side used by the slab driver
+    from aind_exaspim_image_compression.distributed import offset_exact_in_fp32
+    assert [offset_exact_in_fp32(o) for o in (0.0, 37.0, 100.5, 0.0078125, 36.73, 0.3, 70000.0)] == \
+        [True, True, True, True, False, False, False]

@@ -43,6 +43,38 @@ def test_group_transform_parseval_and_inverse(oracle, K):
         assert np.abs(C).sum() - abs(C[0, 0, 0, 0]) < 1e-2
 
 
+def _haar_matrix(K):
+    """Orthonormal Haar analysis matrix of the specification: approximations
+    first, recursively; float64."""
+    if K == 1:
+        return np.ones((1, 1))
+    c = 1.0 / np.sqrt(2.0)
+    a = np.zeros((K // 2, K))
+    d = np.zeros((K // 2, K))
+    for i in range(K // 2):
+        a[i, 2 * i] = a[i, 2 * i + 1] = c
+        d[i, 2 * i], d[i, 2 * i + 1] = c, -c
+    return np.vstack([_haar_matrix(K // 2) @ a, d])
+
+
+@pytest.mark.parametrize("K", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("port", [False, True])
+def test_group_transform_is_the_dct_haar_of_the_definition(oracle, K, port):
+    """The folded 36-operation butterfly of DESIGN.md 3.5 IS the transform it claims to be: the
+    oracle's (and the CPU port's) group transform against the float64 definition
+    Haar_K (x) DCT-II_8 (x) DCT-II_8 (x) DCT-II_8 built from the textbook formula -- not from the
+    oracle's own table (test_tables pins that separately)."""
+    n = np.arange(8)
+    D = np.sqrt(2.0 / 8.0) * np.cos(np.pi * (2 * n[None, :] + 1) * n[:, None] / 16.0)
+    D[0] /= np.sqrt(2.0)
+    g = np.random.default_rng(100 + K).normal(size=(K, 8, 8, 8)).astype(np.float32)
+    want = np.einsum("kj,ua,vb,wc,jabc->kuvw", _haar_matrix(K), D, D, D, g.astype(np.float64))
+    got = oracle.group_transform(g, port=port)
+    assert np.max(np.abs(got - want)) < 2e-6 * max(1.0, np.sqrt(K))     # measured 6e-7
+    back = oracle.group_transform(want.astype(np.float32), inverse=True, port=port)
+    assert np.max(np.abs(back - g)) < 4e-6
+
+
 def test_match_table_invariants(oracle):
     vol, _ = synth_volume((32, 36, 40), seed=2)
     keys = oracle.blockmatch(vol, SIGMA, 3.0)
