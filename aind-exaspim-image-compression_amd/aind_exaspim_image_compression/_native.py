@@ -125,7 +125,7 @@ SIGNATURES = {
     "exabm4d_codec_volume_bound": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
     "exabm4d_codec_encode_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp, _SZ, c_vp, c_vp,
                                       c_vp]),
-    "exabm4d_codec_decode_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp]),
+    "exabm4d_codec_decode_dev": (_I, [_CTX, c_vp, _SZ, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp]),
     "exabm4d_u16_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
     "exabm4d_key_histogram_dev": (_I, [_CTX, c_vp, _I, _SZ, _I, ctypes.c_double, _I,
                                        ctypes.c_uint64, c_vp]),
@@ -489,11 +489,13 @@ class Context:
             tot.ctypes.data_as(c_vp) if totals else None))
         return (int(tot[0]), int(tot[1])) if totals else None
 
-    def codec_decode(self, data, offsets, typesize, shape, chunk, vol):
+    def codec_decode(self, data, nbytes, offsets, typesize, shape, chunk, vol):
+        """``data``: ``nbytes`` bytes of chunk streams on the device; the decoder never reads
+        outside them, whatever ``offsets`` says (malformed containers raise ValueError)."""
         nz, ny, nx = shape
         self._check(lib().exabm4d_codec_decode_dev(
-            self.handle, _ptr(data), _ptr(offsets), int(typesize), nz, ny, nx, int(chunk[0]),
-            int(chunk[1]), int(chunk[2]), _ptr(vol)))
+            self.handle, _ptr(data), int(nbytes), _ptr(offsets), int(typesize), nz, ny, nx,
+            int(chunk[0]), int(chunk[1]), int(chunk[2]), _ptr(vol)))
 
     # -- background offset + quality metrics (row f-4); inputs on device, scalars to the host ----
     DTYPES = {np.dtype(np.uint16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}

@@ -6,9 +6,10 @@ ratio rounded to two decimals.  The codec is whatever object the caller passes -
 passes ``numcodecs.blosc.Blosc(cname="zstd", clevel=5|6, shuffle=SHUFFLE)`` (``evaluate.py:40``,
 ``scripts/evaluate_bm4dnet.py:140``), which is third-party and not part of this repo.
 
-``utils.chunk_codec.ShuffleRansCodec`` is a codec object of that shape whose arithmetic runs on
-the MI355X (byte shuffle + order-0 rANS per byte plane); given it, ``compute_cratio`` codes all
-chunks in one batched device call.
+``utils.chunk_codec.ExacCodec`` is a codec object of that shape whose arithmetic runs on the
+MI355X (EXAC v2: predictive, context-modelled rANS; ``version=1`` / ``ShuffleRansCodec``: byte
+shuffle + order-0 rANS per byte plane); given it, ``compute_cratio`` codes all chunks in one
+batched device call.
 
 ``shuffled_entropy_cratio`` is the MI355X-side rate floor of that codec: a HIP kernel builds, per 64^3 chunk,
 the histograms of the two byte planes Blosc's SHUFFLE filter produces; the zeroth-order entropy
@@ -28,7 +29,7 @@ def compute_cratio(img, codec, patch_shape=(64, 64, 64)):
         img = img[0, 0]
     img = np.ascontiguousarray(img, dtype=np.uint16)
     if img.ndim == 3 and hasattr(codec, "chunk_sizes"):
-        # a device codec (utils/chunk_codec.ShuffleRansCodec): all chunks in one batched call;
+        # a device codec (utils/chunk_codec.ExacCodec): all chunks in one batched call;
         # the sizes are exactly len(codec.encode(chunk)) of the loop below
         return round(img.nbytes / int(codec.chunk_sizes(img, patch_shape).sum(dtype=np.uint64)), 2)
     raw = 0

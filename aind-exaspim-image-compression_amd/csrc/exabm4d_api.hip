@@ -37,6 +37,7 @@ struct exabm4d_ctx {
     int stage_pairs = 1;       // exabm4d_set_option("stage_pairs"): two waves per group (HT stage)
     int profile = 0;           // exabm4d_set_option("profile")
     int bm_int = 1;            // exabm4d_set_option("bm_int"): integer block matching on uint16 input
+    int codec_version = 2;     // exabm4d_set_option("codec_version"): stream format the encoder writes
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
@@ -316,6 +317,11 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     }
     if (std::strcmp(name, "stage_pairs") == 0) {
         ctx->stage_pairs = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "codec_version") == 0) {
+        if (value != 1 && value != 2) return fail(ctx, EXABM4D_ERR_INVALID, "codec_version must be 1 or 2");
+        ctx->codec_version = value;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "bm_int") == 0) {
@@ -968,7 +974,7 @@ int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, in
                              uint64_t* offsets_dev, uint32_t* sizes_dev, uint64_t* totals_host) {
     if (!ctx || !vol) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
     CodecGeom g;
-    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g))
+    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g, ctx->codec_version))
         return fail(ctx, EXABM4D_ERR_INVALID, "codec: typesize must be 2 or 4, sizes >= 1, chunk <= 2^28 elements");
     if (out && !offsets_dev) return fail(ctx, EXABM4D_ERR_INVALID, "codec: offsets_dev is required with out");
     if (out && out_capacity < codec_volume_bound(g))
@@ -998,21 +1004,32 @@ int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, in
     }
     return EXABM4D_OK;
 }
-int exabm4d_codec_decode_dev(exabm4d_ctx* ctx, const uint8_t* in, const uint64_t* offsets_dev,
+int exabm4d_codec_decode_dev(exabm4d_ctx* ctx, const uint8_t* in, size_t in_bytes, const uint64_t* offsets_dev,
                              int typesize, int nz, int ny, int nx, int cz, int cy, int cx, void* vol) {
     if (!ctx || !in || !offsets_dev || !vol) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
-    CodecGeom g;
-    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g))
-        return fail(ctx, EXABM4D_ERR_INVALID, "codec: typesize must be 2 or 4, sizes >= 1, chunk <= 2^28 elements");
     if ((uintptr_t)in & 15) return fail(ctx, EXABM4D_ERR_INVALID, "codec: in must be 16-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the format version is the third byte of every chunk stream: look at the first one
+    uint64_t first[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(first, offsets_dev, sizeof first, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (first[0] > first[1] || first[1] > in_bytes || first[1] - first[0] < 4)
+        return fail(ctx, EXABM4D_ERR_INVALID, "codec: malformed chunk stream (offsets outside the buffer)");
+    uint8_t magic[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(magic, in + first[0], 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (magic[0] != 'E' || magic[1] != 'X' || (magic[2] != 1 && magic[2] != 2))
+        return fail(ctx, EXABM4D_ERR_INVALID, "codec: malformed chunk stream (not an EXAC v1 / v2 stream)");
+    CodecGeom g;
+    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g, magic[2]))
+        return fail(ctx, EXABM4D_ERR_INVALID, "codec: typesize must be 2 or 4, sizes >= 1, chunk <= 2^28 elements");
     uint32_t *sizes, *status;
     unsigned long long *offsets, *totals;
     int rc = codec_aux(ctx, g.nchunks, sizes, offsets, totals, status);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemsetAsync(status, 0, 16, ctx->stream));
-    HIP_TRY(ctx, launch_rans_decode(in, reinterpret_cast<const unsigned long long*>(offsets_dev), g, vol,
-                                    status, ctx->stream));
+    HIP_TRY(ctx, launch_rans_decode(in, in_bytes, reinterpret_cast<const unsigned long long*>(offsets_dev), g,
+                                    vol, status, ctx->stream));
     uint32_t st = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&st, status, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -98,8 +98,9 @@ struct CodecGeom {
     size_t slot_hdr;         // scratch slot of one chunk: header + tables ...
     size_t slot_plane;       // ... then `ts` stream regions of this many bytes
     size_t slot_bytes;
+    int version;             // stream format: 1 = byte planes, 2 = predictive context model (3.11b)
 };
-int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g);
+int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g, int version = 2);
 size_t codec_chunk_bound(size_t n, int ts);
 size_t codec_volume_bound(const CodecGeom& g);
 void codec_fill_rcp_table(uint32_t* tab /* [4097][2]: reciprocal, shift */);
@@ -107,7 +108,15 @@ void codec_fill_rcp_table(uint32_t* tab /* [4097][2]: reciprocal, shift */);
 hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
                               uint32_t* sizes, unsigned long long* offsets, unsigned long long* totals,
                               uint8_t* out, hipStream_t s);
-hipError_t launch_rans_decode(const uint8_t* in, const unsigned long long* offsets, const CodecGeom& g,
-                              void* vol, uint32_t* status, hipStream_t s);
+hipError_t launch_rans_decode(const uint8_t* in, size_t in_bytes, const unsigned long long* offsets,
+                              const CodecGeom& g, void* vol, uint32_t* status, hipStream_t s);
+// EXAC v2 (rans2_kernels.hip); stage 0: code every chunk into its slot, stage 1: pack the slots
+size_t codec2_chunk_bound(size_t n, int ts);
+void codec2_slot_layout(size_t chunk_elems, int ts, size_t& slot_hdr, size_t& slot_bytes);
+hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
+                               uint32_t* sizes, uint8_t* out, const unsigned long long* offsets, int stage,
+                               hipStream_t s);
+hipError_t launch_rans2_decode(const uint8_t* in, size_t in_bytes, const unsigned long long* offsets,
+                               const CodecGeom& g, void* vol, uint32_t* status, hipStream_t s);
 
 }  // namespace exabm4d

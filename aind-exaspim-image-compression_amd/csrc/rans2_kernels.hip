@@ -1,0 +1,594 @@
+// rans2_kernels.hip -- EXAC v2 chunk coder (oracle/exac_codec.c states the format and
+// the kernels' bytes are bit-identical to it): every element is predicted from the voxel above and
+// the voxel in the plane before, the zigzag residual is split into a 64-symbol alphabet (32 direct
+// values + one symbol per octave with the mantissa as raw bits), and the symbol is coded with one of
+// 16 static tables chosen by the neighbours' residual magnitudes -- all of it through the 64
+// interleaved rANS states of v1, lane = state, row of 64 elements = one coalesced wave access.
+// Replaces the arithmetic behind `len(codec.encode(chunk))` of the reference's compute_cratio
+// (utils/img_util.py:401-441; its codec is third-party Blosc-zstd, evaluate.py:40).
+//
+// Integer work only.  One workgroup = one chunk = one wave: pass 1 counts (context, symbol) pairs in
+// LDS, the wave turns the 16 histograms into tables (lane = symbol), pass 2 walks the rows from the
+// last to the first and appends renormalisation words with a ballot + mbcnt rank.
+#include "exabm4d_kernels.h"
+#include "rans_common.h"
+
+namespace exabm4d {
+
+namespace {
+
+constexpr int NCTX = 16, NSYM = 64;
+constexpr uint32_t TAP_LIMIT = 8000u;     // largest tap distance (elements) the format uses
+constexpr int HDR2 = 276;                 // magic, n, ey, ex, nwords, present[16], wide[16]
+constexpr int TAB2_MAX = NCTX * NSYM * 2;
+constexpr int SLOT2_TABLEN = HDR2 + TAB2_MAX;          // u32: table bytes of the chunk (scratch only)
+constexpr uint32_t RING = 8192u;          // decoder history (elements); >= TAP_LIMIT + 2 * 64
+
+// activity -> context: number of edges {1,2,3,4,5,6,8,10,13,17,22,30,45,70,120} that are <= a
+__device__ __forceinline__ uint32_t ctx_of_activity(uint32_t a) {
+    uint32_t c = a < 7u ? a : 6u;
+    c += (a >= 8u) + (a >= 10u) + (a >= 13u) + (a >= 17u) + (a >= 22u) + (a >= 30u) + (a >= 45u) + (a >= 70u) +
+         (a >= 120u);
+    return c;
+}
+
+__device__ __forceinline__ uint32_t mag_of(uint32_t u) {
+    return min((u >> 1) + (u & 1u), 127u);
+}
+
+// chunk-local coordinates of the elements of a row
+struct RowPos {
+    uint32_t z, y, x;
+};
+
+template <int TS>
+struct Taps {
+    // geometry of one chunk (wave-uniform)
+    uint32_t ex, ey, plane, n;
+    size_t sy, sz;              // volume strides (elements) of y and z
+    bool wide_x, wide_p;        // ex >= 64 / plane >= 64: tap multiples are 1 for every lane
+
+    // which taps element (i; z, y) uses, and their multiples
+    __device__ __forceinline__ void flags(uint32_t i, uint32_t z, uint32_t y, bool act, bool& U, bool& B,
+                                          uint32_t& ku, uint32_t& kb) const {
+        const uint32_t lane = i & 63u;
+        ku = wide_x ? 1u : lane / ex + 1u;
+        kb = wide_p ? 1u : lane / plane + 1u;
+        U = act && y >= ku && ku * ex <= TAP_LIMIT;
+        B = act && z >= kb && (uint64_t)kb * plane <= TAP_LIMIT;
+    }
+
+    // zigzag residual of element i at volume offset `off` (relative to the chunk's first element)
+    __device__ __forceinline__ uint32_t resid(const void* __restrict__ vol, size_t base, uint32_t i, uint32_t z,
+                                              uint32_t y, size_t off, bool act) const {
+        if (TS == 4) {
+            const int32_t v = static_cast<const int32_t*>(vol)[base + (act ? off : 0)];
+            return act ? ((uint32_t)v << 1) ^ (uint32_t)(v >> 31) : 0u;
+        }
+        bool U, B;
+        uint32_t ku, kb;
+        flags(i, z, y, act, U, B, ku, kb);
+        const uint16_t* v16 = static_cast<const uint16_t*>(vol) + base;
+        const uint32_t v = v16[act ? off : 0];
+        const uint32_t vu = v16[U ? off - (size_t)ku * sy : 0];
+        const uint32_t vb = v16[B ? off - (size_t)kb * sz : 0];
+        const uint32_t pred = U && B ? (vu + vb + 1u) >> 1 : (U ? vu : (B ? vb : 0u));
+        const int32_t r = (int32_t)(int16_t)(uint16_t)(v - pred);
+        return act ? (uint32_t)(((r << 1) ^ (r >> 15)) & 0xFFFF) : 0u;
+    }
+};
+
+struct Model {
+    uint32_t s, nb, e, ctx;
+};
+
+// symbol, raw-bit count and raw value of a zigzag residual
+__device__ __forceinline__ void symbol_of(uint32_t u, uint32_t& s, uint32_t& nb, uint32_t& e) {
+    const uint32_t w = u - 32u, t = (w >> 2) + 1u;
+    const uint32_t c = 31u - (uint32_t)__clz((int)t);
+    const bool direct = u < 32u;
+    s = direct ? u : 32u + c;
+    nb = direct ? 0u : 2u + c;
+    e = direct ? 0u : w - (((1u << c) - 1u) << 2);
+}
+
+// (symbol, raw bits, context) of element i = 64 r + lane of the chunk; coordinates from the caller
+template <int TS>
+__device__ __forceinline__ Model model_of(const void* __restrict__ vol, size_t base, const Taps<TS>& t, uint32_t i,
+                                          const RowPos& p, bool act) {
+    const size_t off = (size_t)p.z * t.sz + (size_t)p.y * t.sy + p.x;
+    bool U, B;
+    uint32_t ku, kb;
+    t.flags(i, p.z, p.y, act, U, B, ku, kb);
+    const uint32_t u = t.resid(vol, base, i, p.z, p.y, off, act);
+    // the taps' own residuals (their lanes, hence their tap multiples, are their own)
+    const uint32_t ju = i - ku * t.ex, jb = i - kb * t.plane;
+    const uint32_t mu = mag_of(t.resid(vol, base, ju, p.z, p.y - ku, off - (size_t)ku * t.sy, U));
+    const uint32_t mb = mag_of(t.resid(vol, base, jb, p.z - kb, p.y, off - (size_t)kb * t.sz, B));
+    const uint32_t a = U && B ? mu + mb : (U ? 2u * mu : (B ? 2u * mb : 0u));
+    Model m;
+    symbol_of(u, m.s, m.nb, m.e);
+    m.ctx = ctx_of_activity(a);
+    return m;
+}
+
+// coordinates of element i of a chunk whose rows do not line up with the volume's x-rows
+__device__ __forceinline__ RowPos pos_of(uint32_t i, uint32_t ex, uint32_t ey) {
+    RowPos p;
+    p.x = i % ex;
+    const uint32_t t = i / ex;
+    p.y = t % ey;
+    p.z = t / ey;
+    return p;
+}
+
+// one rANS step: renormalise (append the low word of the lanes that must, in lane order), then
+// x = (x / f) * 4096 + x mod f + c with the division as a multiply-high by `rcp` >> `shift`
+__device__ __forceinline__ void renorm_put(uint32_t& x, uint32_t f, bool act, uint16_t* __restrict__ out,
+                                           uint32_t& nwords) {
+    const bool emit = act && x >= (f << 19);
+    const uint64_t em = __ballot(emit);
+    if (emit) {
+        out[nwords + rank_below(em)] = (uint16_t)(x & 0xFFFFu);
+        x >>= 16;
+    }
+    nwords += (uint32_t)__popcll(em);
+}
+
+#ifndef EXABM4D_ENC2_RB
+#define EXABM4D_ENC2_RB 4       // rows whose loads are in flight together
+#endif
+#ifndef EXABM4D_ENC2_NC
+#define EXABM4D_ENC2_NC 2       // copies of every histogram counter (copy = lane mod NC)
+#endif
+
+}  // namespace
+
+// ---- encode ---------------------------------------------------------------------------------------------------
+// Slot (scratch, per chunk): [0, 276) header, [276, 276 + 2048) table bytes, u32 table length at
+// SLOT2_TABLEN, 16-bit words from g.slot_hdr.
+template <int TS>
+__global__ __launch_bounds__(64) void rans2_encode_kernel(const void* __restrict__ vol, CodecGeom g,
+                                                          const uint2* __restrict__ rcp_tab,
+                                                          uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes) {
+    constexpr int NC = EXABM4D_ENC2_NC, RB = EXABM4D_ENC2_RB;
+    __shared__ uint32_t hist[NCTX * NSYM * NC];
+    __shared__ uint2 etab[NCTX * NSYM];
+    const int c = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t n = b.n;
+    const uint32_t rows = (n + 63u) >> 6;
+    const bool fast = (b.ex & 63) == 0;
+    Taps<TS> t;
+    t.ex = (uint32_t)b.ex;
+    t.ey = (uint32_t)b.ey;
+    t.plane = t.ex * t.ey;
+    t.n = n;
+    t.sy = (size_t)g.nx;
+    t.sz = (size_t)g.nx * g.ny;
+    t.wide_x = t.ex >= 64u;
+    t.wide_p = t.plane >= 64u;
+    RowCursor rc;
+    rc.rpx = (uint32_t)b.ex >> 6;
+    rc.ey = (uint32_t)b.ey;
+    uint8_t* slot = slots + (size_t)c * g.slot_bytes;
+
+#pragma unroll
+    for (int j = 0; j < NCTX * NC; j++) hist[64 * j + lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    auto row_pos = [&](uint32_t r) -> RowPos {
+        RowPos p;
+        if (fast) {
+            p.x = rc.xr * 64u + lane;
+            p.y = rc.y;
+            p.z = rc.z;
+        } else {
+            p = pos_of(min(r * 64u + lane, n - 1u), t.ex, t.ey);
+        }
+        return p;
+    };
+
+    // -- pass 1: (context, symbol) histograms ------------------------------------------------------------
+    rc.xr = rc.y = rc.z = 0;
+    for (uint32_t r0 = 0; r0 < rows; r0 += RB) {
+        Model m[RB];
+        bool act[RB];
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+            const uint32_t r = r0 + k, i = r * 64u + lane;
+            act[k] = r < rows && i < n;
+            const RowPos p = row_pos(r);
+            m[k] = model_of<TS>(vol, b.base, t, i, p, act[k]);
+            if (fast && r < rows) rc.next();
+        }
+#pragma unroll
+        for (int k = 0; k < RB; k++)
+            if (act[k]) atomicAdd(&hist[(m[k].ctx * NSYM + m[k].s) * NC + (lane & (NC - 1))], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // -- tables: lane = symbol ----------------------------------------------------------------------------------
+    uint32_t toff = 0;
+    bool coded = false;
+    uint8_t* tab = slot + HDR2;
+    for (int q = 0; q < NCTX; q++) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) cnt += hist[(q * NSYM + lane) * NC + k];
+        const uint32_t tot = wave_sum(cnt);
+        uint32_t F = 0;
+        if (cnt) {
+            const uint32_t f = (uint32_t)(((uint64_t)cnt << RANS_BITS) / tot);
+            F = f < 1u ? 1u : f;
+        }
+        uint32_t sum = wave_sum(F);
+        if (tot) {
+            uint32_t best = wave_max((F << 8) | (63u - lane));
+            const int32_t diff = (int32_t)RANS_M - (int32_t)sum;
+            if ((int32_t)(best >> 8) + diff >= 1) {
+                if (lane == 63u - (best & 255u)) F = (uint32_t)((int32_t)F + diff);
+            } else {
+                while (sum > RANS_M) {
+                    best = wave_max((F << 8) | (63u - lane));
+                    if (lane == 63u - (best & 255u)) F -= 1u;
+                    sum--;
+                }
+            }
+        }
+        const uint64_t pm = __ballot(F != 0u), wm = __ballot(F != 0u && F - 1u >= 256u);
+        const uint32_t np = (uint32_t)__popcll(pm), nw = (uint32_t)__popcll(wm);
+        if (lane == 0) {                                          // (offsets 20 / 148: 4-byte aligned)
+            uint32_t* hp = reinterpret_cast<uint32_t*>(slot + 20) + 2 * q;
+            uint32_t* hw = reinterpret_cast<uint32_t*>(slot + 148) + 2 * q;
+            hp[0] = (uint32_t)pm;
+            hp[1] = (uint32_t)(pm >> 32);
+            hw[0] = (uint32_t)wm;
+            hw[1] = (uint32_t)(wm >> 32);
+        }
+        if (F) tab[toff + rank_below(pm)] = (uint8_t)((F - 1u) & 255u);
+        if (F && F - 1u >= 256u) tab[toff + np + rank_below(wm)] = (uint8_t)((F - 1u) >> 8);
+        toff += np + nw;
+        coded = coded || np > 1u || (pm >> 32) != 0ull;
+        const uint32_t C = wave_excl_scan(F, lane);
+        uint2 e = make_uint2(0u, 0u);
+        if (F) {
+            const uint2 rs = rcp_tab[F];
+            const uint32_t bias = F == 1u ? C + RANS_M - 1u : C;
+            e.x = F | (bias << 13) | (rs.y << 26);
+            e.y = rs.x;
+        }
+        etab[q * NSYM + lane] = e;
+    }
+    if (toff & 1u) {
+        if (lane == 0) tab[toff] = 0;
+        toff++;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // -- pass 2: rows from the last to the first ------------------------------------------------------------
+    uint32_t nwords = 0, x = RANS_L;
+    uint16_t* out = reinterpret_cast<uint16_t*>(slot + g.slot_hdr);
+    if (coded) {
+        if (fast && rows) rc.seek(rows - 1);
+        for (uint32_t rb = ((rows + RB - 1) / RB) * RB; rb > 0; rb -= RB) {
+            Model m[RB];
+            bool act[RB];
+            uint2 e[RB];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const uint32_t r = rb - 1 - k, i = r * 64u + lane;
+                act[k] = r < rows && i < n;
+                const RowPos p = row_pos(r);
+                m[k] = model_of<TS>(vol, b.base, t, i, p, act[k]);
+                if (fast && r < rows) rc.prev();
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++) e[k] = etab[m[k].ctx * NSYM + m[k].s];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                // raw bits, last step first (the decoder reads them low bits first)
+#pragma unroll
+                for (int j = (TS == 2 ? 1 : 2); j >= 0; j--) {
+                    const bool has = act[k] && m[k].nb > 12u * (uint32_t)j;
+                    if (__ballot(has) == 0ull) continue;
+                    const uint32_t kk = min(m[k].nb - 12u * (uint32_t)j, 12u);      // garbage where !has
+                    const uint32_t f = RANS_M >> (has ? kk : 0u);
+                    renorm_put(x, f, has, out, nwords);
+                    if (has) {
+                        const uint32_t val = (m[k].e >> (12 * j)) & ((1u << kk) - 1u);
+                        x = ((x >> (12u - kk)) << RANS_BITS) | (x & (f - 1u)) | (val << (12u - kk));
+                    }
+                }
+                const uint32_t f = e[k].x & 0x1FFFu;
+                renorm_put(x, f, act[k], out, nwords);
+                if (act[k]) {
+                    const uint32_t qd = __umulhi(x, e[k].y) >> (e[k].x >> 26);
+                    x = x + ((e[k].x >> 13) & 0x1FFFu) + qd * (RANS_M - f);
+                }
+            }
+        }
+        out[nwords + 2 * lane] = (uint16_t)(x & 0xFFFFu);
+        out[nwords + 2 * lane + 1] = (uint16_t)(x >> 16);
+        nwords += 128;
+    }
+    if (lane == 0) {
+        slot[0] = 'E';
+        slot[1] = 'X';
+        slot[2] = 2;
+        slot[3] = (uint8_t)TS;
+        uint32_t* h = reinterpret_cast<uint32_t*>(slot);
+        h[1] = n;
+        h[2] = t.ey;
+        h[3] = t.ex;
+        h[4] = nwords;
+        *reinterpret_cast<uint32_t*>(slot + SLOT2_TABLEN) = toff;
+        sizes[c] = (uint32_t)HDR2 + toff + 2u * nwords;
+    }
+}
+
+// slot -> packed stream at out + offsets[c]: header + tables (an even number of bytes), then the words
+__global__ __launch_bounds__(256) void rans2_pack_kernel(const uint8_t* __restrict__ slots, CodecGeom g,
+                                                         const unsigned long long* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ sizes,
+                                                         uint8_t* __restrict__ out) {
+    const int c = blockIdx.x;
+    const uint8_t* slot = slots + (size_t)c * g.slot_bytes;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out + offsets[c]);
+    const uint32_t head = ((uint32_t)HDR2 + *reinterpret_cast<const uint32_t*>(slot + SLOT2_TABLEN)) / 2u;
+    const uint32_t nw = reinterpret_cast<const uint32_t*>(slot)[4];
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(slot);
+    for (uint32_t i = threadIdx.x; i < head; i += 256) dst[i] = src[i];
+    src = reinterpret_cast<const uint16_t*>(slot + g.slot_hdr);
+    for (uint32_t i = threadIdx.x; i < nw; i += 256) dst[head + i] = src[i];
+    const uint32_t sz = sizes[c], padded = (sz + 15u) & ~15u;
+    for (uint32_t i = sz / 2 + threadIdx.x; i < padded / 2; i += 256) dst[i] = 0;
+}
+
+// ---- decode: one wave per chunk ------------------------------------------------------------------------------
+// status bits: 1 header / sizes, 2 tables, 4 word stream exhausted, 8 offsets, 16 symbol out of range
+template <int TS>
+__global__ __launch_bounds__(64) void rans2_decode_kernel(const uint8_t* __restrict__ in, size_t in_bytes,
+                                                          const unsigned long long* __restrict__ offsets,
+                                                          CodecGeom g, void* __restrict__ vol,
+                                                          uint32_t* __restrict__ status) {
+    __shared__ uint16_t cum[NCTX * (NSYM + 1)];
+    __shared__ uint8_t mring[RING];
+    __shared__ uint16_t vring[TS == 2 ? RING : 1];
+    const int c = blockIdx.x;
+    const uint32_t lane = lane_id();
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t n = b.n;
+    const uint32_t rows = (n + 63u) >> 6;
+    const bool fast = (b.ex & 63) == 0;
+    const unsigned long long o0 = offsets[c], o1 = offsets[c + 1];
+    if (o0 > o1 || o1 > in_bytes || (o0 & 1ull)) {
+        if (lane == 0) atomicOr(status, 8u);
+        return;
+    }
+    const uint8_t* s0 = in + o0;
+    const size_t avail = (size_t)(o1 - o0);
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(s0);
+    bool ok = avail >= (size_t)HDR2 && s0[0] == 'E' && s0[1] == 'X' && s0[2] == 2 && s0[3] == TS && h[1] == n &&
+              h[2] == (uint32_t)b.ey && h[3] == (uint32_t)b.ex;
+    if (!ok) {
+        if (lane == 0) atomicOr(status, 1u);
+        return;
+    }
+    const uint32_t nwords = h[4];
+    // table sizes: lane q < 16 owns context q
+    uint64_t pm = 0, wm = 0;
+    if (lane < NCTX) {
+        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(s0 + 20) + 2 * lane;
+        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(s0 + 148) + 2 * lane;
+        pm = (uint64_t)p32[0] | ((uint64_t)p32[1] << 32);
+        wm = (uint64_t)w32[0] | ((uint64_t)w32[1] << 32);
+    }
+    const uint32_t tsz = (uint32_t)__popcll(pm) + (uint32_t)__popcll(wm);
+    const uint32_t tstart = wave_excl_scan(tsz, lane);
+    const uint32_t ttot = wave_sum(tsz), tpad = (ttot + 1u) & ~1u;
+    ok = __ballot((wm & ~pm) != 0ull) == 0ull && (size_t)HDR2 + tpad + 2 * (size_t)nwords <= avail &&
+         (nwords == 0u || nwords >= 128u);
+    if (!ok) {
+        if (lane == 0) atomicOr(status, 1u);
+        return;
+    }
+    if (n == 0) return;
+    const uint8_t* tab = s0 + HDR2;
+    bool tables_ok = true;
+    for (int q = 0; q < NCTX; q++) {
+        const uint64_t pq = __shfl(pm, q, 64), wq = __shfl(wm, q, 64);
+        const uint32_t tq = __shfl(tstart, q, 64), np = (uint32_t)__popcll(pq);
+        uint32_t F = 0;
+        if ((pq >> lane) & 1ull) {
+            F = tab[tq + rank_below(pq)];
+            if ((wq >> lane) & 1ull) F |= (uint32_t)tab[tq + np + rank_below(wq)] << 8;
+            F += 1u;
+        }
+        const uint32_t C = wave_excl_scan(F, lane);
+        const uint32_t sum = wave_sum(F);
+        cum[q * (NSYM + 1) + lane] = (uint16_t)C;
+        if (lane == 63) cum[q * (NSYM + 1) + NSYM] = (uint16_t)min(sum, 0xFFFFu);
+        tables_ok = tables_ok && (np == 0u || sum == RANS_M);
+    }
+    if (!tables_ok) {
+        if (lane == 0) atomicOr(status, 2u);
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    Taps<TS> t;
+    t.ex = (uint32_t)b.ex;
+    t.ey = (uint32_t)b.ey;
+    t.plane = t.ex * t.ey;
+    t.n = n;
+    t.sy = (size_t)g.nx;
+    t.sz = (size_t)g.nx * g.ny;
+    t.wide_x = t.ex >= 64u;
+    t.wide_p = t.plane >= 64u;
+    RowCursor rc;
+    rc.rpx = (uint32_t)b.ex >> 6;
+    rc.ey = (uint32_t)b.ey;
+    rc.xr = rc.y = rc.z = 0;
+
+    const uint16_t* words = reinterpret_cast<const uint16_t*>(s0 + HDR2 + tpad);
+    uint32_t cursor = nwords ? nwords - 128u : 0u;
+    uint32_t x = RANS_L;
+    if (nwords) x = (uint32_t)words[cursor + 2 * lane] | ((uint32_t)words[cursor + 2 * lane + 1] << 16);
+    uint32_t bad = 0;
+    // renormalise the lanes that need it: take their words in lane order from below the cursor
+    auto refill = [&](bool need) -> bool {
+        const uint64_t nm = __ballot(need);
+        const uint32_t k = (uint32_t)__popcll(nm);
+        if (k > cursor) return false;
+        cursor -= k;
+        if (need) x = (x << 16) | words[cursor + rank_below(nm)];
+        return true;
+    };
+    for (uint32_t r = 0; r < rows; r++) {
+        const uint32_t i = r * 64u + lane;
+        const bool act = i < n;
+        RowPos p;
+        if (fast) {
+            p.x = rc.xr * 64u + lane;
+            p.y = rc.y;
+            p.z = rc.z;
+            rc.next();
+        } else {
+            p = pos_of(min(i, n - 1u), t.ex, t.ey);
+        }
+        bool U, B;
+        uint32_t ku, kb;
+        t.flags(i, p.z, p.y, act, U, B, ku, kb);
+        const uint32_t ju = (i - ku * t.ex) & (RING - 1u), jb = (i - kb * t.plane) & (RING - 1u);
+        const uint32_t mu = U ? mring[ju] : 0u, mb = B ? mring[jb] : 0u;
+        const uint32_t a = U && B ? mu + mb : (U ? 2u * mu : (B ? 2u * mb : 0u));
+        const uint32_t q = ctx_of_activity(a);
+        uint32_t pred = 0;
+        if (TS == 2) {
+            const uint32_t vu = U ? vring[ju] : 0u, vb = B ? vring[jb] : 0u;
+            pred = U && B ? (vu + vb + 1u) >> 1 : (U ? vu : vb);
+        }
+        // (1) symbol: binary search of the slot in the context's cumulative table
+        uint32_t s = 0, nb = 0, e = 0;
+        bool need = false;
+        if (act) {
+            const uint16_t* cq = cum + q * (NSYM + 1);
+            const uint32_t slot = x & (RANS_M - 1u);
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                if (cq[s + step] <= slot) s += step;
+            const uint32_t C = cq[s], F = (uint32_t)cq[s + 1] - C;
+            if (F == 0u) bad |= 2u;            // a context the encoder never used
+            x = F * (x >> RANS_BITS) + slot - C;
+            nb = s < 32u ? 0u : s - 30u;
+            need = x < RANS_L;
+        }
+        if (!refill(need)) {
+            bad |= 4u;
+            break;
+        }
+        // (2) raw bits, low step first
+        bool under = false;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const bool has = act && nb > 12u * (uint32_t)j;
+            if (__ballot(has) == 0ull) break;
+            need = false;
+            if (has) {
+                const uint32_t kk = min(nb - 12u * (uint32_t)j, 12u), f = RANS_M >> kk;
+                const uint32_t slot = x & (RANS_M - 1u);
+                e |= (slot >> (12u - kk)) << (12 * j);
+                x = f * (x >> RANS_BITS) + (slot & (f - 1u));
+                need = x < RANS_L;
+            }
+            if (!refill(need)) {
+                under = true;
+                break;
+            }
+        }
+        if (under) {
+            bad |= 4u;
+            break;
+        }
+        // (3) value
+        if (act) {
+            uint64_t u = s;
+            if (s >= 32u) {
+                const uint32_t cc = s - 32u;
+                u = 32ull + ((((uint64_t)1 << cc) - 1ull) << 2) + e;
+                if (cc > 29u || (TS == 2 && cc > 13u) || u > (TS == 2 ? 0xFFFFull : 0xFFFFFFFFull)) {
+                    bad |= 16u;
+                    u = 0;
+                }
+            }
+            const uint32_t u32 = (uint32_t)u;
+            mring[i & (RING - 1u)] = (uint8_t)mag_of(u32);
+            const size_t off = (size_t)p.z * t.sz + (size_t)p.y * t.sy + p.x;
+            if (TS == 2) {
+                const uint32_t r16 = (u32 >> 1) ^ (0u - (u32 & 1u));
+                const uint16_t v = (uint16_t)(pred + r16);
+                vring[i & (RING - 1u)] = v;
+                static_cast<uint16_t*>(vol)[b.base + off] = v;
+            } else {
+                static_cast<int32_t*>(vol)[b.base + off] = (int32_t)((u32 >> 1) ^ (0u - (u32 & 1u)));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint64_t bm = __ballot(bad != 0u);
+    if (bm) {
+        uint32_t all = bad;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) all |= (uint32_t)__shfl_xor(all, o, 64);
+        if (lane == 0) atomicOr(status, all);
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+size_t codec2_chunk_bound(size_t n, int ts) {
+    // header, worst-case tables, one word per coding step (symbol + 2 / 3 raw steps) + final states
+    return (size_t)HDR2 + TAB2_MAX + 2 * ((size_t)(ts == 2 ? 3 : 4) * n + 128);
+}
+
+void codec2_slot_layout(size_t chunk_elems, int ts, size_t& slot_hdr, size_t& slot_bytes) {
+    slot_hdr = ((size_t)SLOT2_TABLEN + 4 + 15) & ~(size_t)15;
+    slot_bytes = slot_hdr + ((2 * ((size_t)(ts == 2 ? 3 : 4) * chunk_elems + 128) + 15) & ~(size_t)15);
+}
+
+hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
+                               uint32_t* sizes, uint8_t* out, const unsigned long long* offsets, int stage,
+                               hipStream_t s) {
+    const uint2* rt = reinterpret_cast<const uint2*>(rcp_tab);
+    if (stage == 0) {
+        if (g.ts == 2)
+            hipLaunchKernelGGL(rans2_encode_kernel<2>, dim3((unsigned)g.nchunks), dim3(64), 0, s, vol, g, rt, slots,
+                               sizes);
+        else
+            hipLaunchKernelGGL(rans2_encode_kernel<4>, dim3((unsigned)g.nchunks), dim3(64), 0, s, vol, g, rt, slots,
+                               sizes);
+    } else {
+        hipLaunchKernelGGL(rans2_pack_kernel, dim3((unsigned)g.nchunks), dim3(256), 0, s, slots, g, offsets, sizes,
+                           out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rans2_decode(const uint8_t* in, size_t in_bytes, const unsigned long long* offsets,
+                               const CodecGeom& g, void* vol, uint32_t* status, hipStream_t s) {
+    if (g.ts == 2)
+        hipLaunchKernelGGL(rans2_decode_kernel<2>, dim3((unsigned)g.nchunks), dim3(64), 0, s, in, in_bytes, offsets,
+                           g, vol, status);
+    else
+        hipLaunchKernelGGL(rans2_decode_kernel<4>, dim3((unsigned)g.nchunks), dim3(64), 0, s, in, in_bytes, offsets,
+                           g, vol, status);
+    return hipGetLastError();
+}
+
+}  // namespace exabm4d

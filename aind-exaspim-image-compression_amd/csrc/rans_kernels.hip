@@ -8,75 +8,11 @@
 // Integer work only: HBM/LDS-bound, no MFMA.  A row of a chunk (64 elements) is one coalesced
 // wave load; the emitted 16-bit words of a row are compacted with a ballot + mbcnt rank.
 #include "exabm4d_kernels.h"
+#include "rans_common.h"
 
 namespace exabm4d {
 
 namespace {
-
-constexpr uint32_t RANS_L = 1u << 15;
-constexpr int RANS_BITS = 12;
-constexpr uint32_t RANS_M = 1u << RANS_BITS;
-constexpr int HDR_TABLE = 32 + 512;   // bitmap + up to 256 frequencies, per plane, in a slot
-
-struct ChunkBox {
-    size_t base;        // element index of the chunk's first element in the volume
-    int ey, ex;         // extent of this chunk along y, x
-    uint32_t n;         // elements in this chunk
-};
-
-__device__ __forceinline__ ChunkBox chunk_box(const CodecGeom& g, int c) {
-    const int bx = c % g.gx, by = (c / g.gx) % g.gy, bz = c / (g.gx * g.gy);
-    const int z0 = bz * g.cz, y0 = by * g.cy, x0 = bx * g.cx;
-    const int ez = min(g.cz, g.nz - z0), ey = min(g.cy, g.ny - y0), ex = min(g.cx, g.nx - x0);
-    ChunkBox b;
-    b.base = ((size_t)z0 * g.ny + y0) * g.nx + x0;
-    b.ey = ey;
-    b.ex = ex;
-    b.n = (uint32_t)ez * (uint32_t)ey * (uint32_t)ex;
-    return b;
-}
-
-// element offset (in the volume, relative to the chunk's first element) of chunk element i
-__device__ __forceinline__ size_t elem_offset(const CodecGeom& g, const ChunkBox& b, uint32_t i) {
-    const uint32_t x = i % (uint32_t)b.ex, t = i / (uint32_t)b.ex;
-    const uint32_t y = t % (uint32_t)b.ey, z = t / (uint32_t)b.ey;
-    return ((size_t)z * g.ny + y) * g.nx + x;
-}
-
-// Rows of 64 consecutive chunk elements when the chunk's x extent is a multiple of 64: a row is
-// then 64 consecutive elements of one x-row of the volume, and walking the rows forwards or
-// backwards only needs three wave-uniform counters (no per-lane division).
-struct RowCursor {
-    uint32_t xr, y, z;      // 64-element segment inside the x-row, y, z of the current row
-    uint32_t rpx, ey;       // segments per x-row, chunk extent along y
-    __device__ __forceinline__ void seek(uint32_t r) {
-        xr = r % rpx;
-        const uint32_t t = r / rpx;
-        y = t % ey;
-        z = t / ey;
-    }
-    __device__ __forceinline__ void next() {
-        if (++xr == rpx) {
-            xr = 0;
-            if (++y == ey) {
-                y = 0;
-                z++;
-            }
-        }
-    }
-    __device__ __forceinline__ void prev() {
-        if (xr-- == 0) {
-            xr = rpx - 1;
-            if (y-- == 0) {
-                y = ey - 1;
-                z--;
-            }
-        }
-    }
-    __device__ __forceinline__ size_t offset(const CodecGeom& g) const {
-        return ((size_t)z * g.ny + y) * g.nx + xr * 64u;
-    }
-};
 
 #ifndef EXABM4D_ENC_NC
 #define EXABM4D_ENC_NC 2        // copies of the encoder's histogram counters (power of two; 1: 6.3 + 8.4 ms, 2: 5.0 + 8.4, 4: 5.4 + 11.0 -- LDS per workgroup)
@@ -84,40 +20,6 @@ struct RowCursor {
 #ifndef EXABM4D_ENC_PP
 #define EXABM4D_ENC_PP 2        // byte planes per wave of the encoder (1: one wave per plane)
 #endif
-template <int TS>
-__device__ __forceinline__ uint32_t load_bits(const void* vol, size_t e) {
-    if (TS == 2) return static_cast<const uint16_t*>(vol)[e];
-    const int32_t v = static_cast<const int32_t*>(vol)[e];
-    return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
-}
-
-__device__ __forceinline__ uint32_t lane_id() {
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-__device__ __forceinline__ uint32_t rank_below(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o, 64));
-    return v;
-}
-// exclusive prefix sum over the lanes of a wave
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
-    uint32_t s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(s, o, 64);
-        if (lane >= (uint32_t)o) s += t;
-    }
-    return s - v;
-}
-
 // Normalised frequencies of one plane from its 256 counts (oracle
 // orc_exac_normalize).  Lane l owns symbols 64 j + l, j = 0..3.
 __device__ __forceinline__ void normalize_plane(const uint32_t (&cnt)[4], uint32_t n, uint32_t lane,
@@ -490,6 +392,7 @@ __global__ __launch_bounds__(256) void rans_pack_kernel(const uint8_t* __restric
 // status[0] is set to a non-zero code by any chunk whose stream is malformed (that chunk is skipped).
 template <int TS>
 __global__ __launch_bounds__(64 * TS) void rans_decode_kernel(const uint8_t* __restrict__ in,
+                                                             size_t in_bytes,
                                                              const unsigned long long* __restrict__ offsets,
                                                              CodecGeom g, void* __restrict__ vol,
                                                              uint32_t* __restrict__ status) {
@@ -506,6 +409,12 @@ __global__ __launch_bounds__(64 * TS) void rans_decode_kernel(const uint8_t* __r
     rc.rpx = (uint32_t)b.ex >> 6;
     rc.ey = (uint32_t)b.ey;
     rc.xr = rc.y = rc.z = 0;
+    // a corrupt container must not turn into out-of-bounds reads: offsets ascending, inside the
+    // buffer, 2-byte aligned (status bit 8)
+    if (offsets[c] > offsets[c + 1] || offsets[c + 1] > in_bytes || (offsets[c] & 1ull)) {
+        if (lane == 0) atomicOr(status, 8u);
+        return;
+    }
     const uint8_t* s0 = in + offsets[c];
     const size_t avail = (size_t)(offsets[c + 1] - offsets[c]);
 
@@ -635,11 +544,15 @@ __global__ __launch_bounds__(256) void unzigzag_kernel(uint32_t* __restrict__ v,
 
 // ---- host side ----------------------------------------------------------------------------------------------
 size_t codec_chunk_bound(size_t n, int ts) {
-    return 8 + 4 * (size_t)ts + (size_t)ts * HDR_TABLE + (size_t)ts * 2 * (n + 128);
+    // either format: callers size their buffers before they choose one
+    const size_t v1 = 8 + 4 * (size_t)ts + (size_t)ts * HDR_TABLE + (size_t)ts * 2 * (n + 128);
+    const size_t v2 = codec2_chunk_bound(n, ts);
+    return v1 > v2 ? v1 : v2;
 }
 
-int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g) {
+int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g, int version) {
     if (ts != 2 && ts != 4) return -1;
+    if (version != 1 && version != 2) return -1;
     if (nz < 1 || ny < 1 || nx < 1 || cz < 1 || cy < 1 || cx < 1) return -1;
     cz = cz < nz ? cz : nz;
     cy = cy < ny ? cy : ny;
@@ -658,6 +571,11 @@ int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, Code
     g.slot_hdr = ((size_t)(8 + 4 * ts + ts * HDR_TABLE) + 15) & ~(size_t)15;
     g.slot_plane = ((size_t)2 * ((size_t)cn + 128) + 15) & ~(size_t)15;
     g.slot_bytes = g.slot_hdr + (size_t)ts * g.slot_plane;
+    g.version = version;
+    if (version == 2) {
+        g.slot_plane = 0;
+        codec2_slot_layout((size_t)cn, ts, g.slot_hdr, g.slot_bytes);
+    }
     return 0;
 }
 
@@ -695,7 +613,10 @@ hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_
                               uint32_t* sizes, unsigned long long* offsets, unsigned long long* totals,
                               uint8_t* out, hipStream_t s) {
     const uint2* rt = reinterpret_cast<const uint2*>(rcp_tab);
-    if (g.ts == 2)
+    if (g.version == 2) {
+        const hipError_t e = launch_rans2_encode(vol, g, rcp_tab, slots, sizes, nullptr, nullptr, 0, s);
+        if (e != hipSuccess) return e;
+    } else if (g.ts == 2)
         hipLaunchKernelGGL((rans_encode_kernel<2, EXABM4D_ENC_PP>), dim3((unsigned)g.nchunks), dim3(128 / EXABM4D_ENC_PP), 0, s, vol, g, rt,
                            slots, sizes);
     else
@@ -703,6 +624,7 @@ hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_
                            slots, sizes);
     hipLaunchKernelGGL(rans_scan_kernel, dim3(1), dim3(1024), 0, s, sizes, g.nchunks, offsets, totals);
     if (out) {
+        if (g.version == 2) return launch_rans2_encode(vol, g, rcp_tab, slots, sizes, out, offsets, 1, s);
         if (g.ts == 2)
             hipLaunchKernelGGL(rans_pack_kernel<2>, dim3((unsigned)g.nchunks), dim3(256), 0, s, slots, g,
                                offsets, sizes, out);
@@ -713,14 +635,15 @@ hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_rans_decode(const uint8_t* in, const unsigned long long* offsets, const CodecGeom& g,
-                              void* vol, uint32_t* status, hipStream_t s) {
+hipError_t launch_rans_decode(const uint8_t* in, size_t in_bytes, const unsigned long long* offsets,
+                              const CodecGeom& g, void* vol, uint32_t* status, hipStream_t s) {
+    if (g.version == 2) return launch_rans2_decode(in, in_bytes, offsets, g, vol, status, s);
     if (g.ts == 2) {
-        hipLaunchKernelGGL(rans_decode_kernel<2>, dim3((unsigned)g.nchunks), dim3(128), 0, s, in, offsets, g,
-                           vol, status);
+        hipLaunchKernelGGL(rans_decode_kernel<2>, dim3((unsigned)g.nchunks), dim3(128), 0, s, in, in_bytes,
+                           offsets, g, vol, status);
     } else {
-        hipLaunchKernelGGL(rans_decode_kernel<4>, dim3((unsigned)g.nchunks), dim3(256), 0, s, in, offsets, g,
-                           vol, status);
+        hipLaunchKernelGGL(rans_decode_kernel<4>, dim3((unsigned)g.nchunks), dim3(256), 0, s, in, in_bytes,
+                           offsets, g, vol, status);
         const size_t n = (size_t)g.nz * g.ny * g.nx;
         const unsigned blocks = (unsigned)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
         hipLaunchKernelGGL(unzigzag_kernel, dim3(blocks), dim3(256), 0, s, static_cast<uint32_t*>(vol), n);

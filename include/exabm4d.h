@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXABM4D_VERSION 200 /* 0.2.0: + chunk coder, chunk-local mode, staged uint16 entry points (round 2) */
+#define EXABM4D_VERSION 300 /* 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
 
 typedef enum exabm4d_status {
     EXABM4D_OK = 0,
@@ -283,32 +283,40 @@ int exabm4d_dctq_inverse_dev(exabm4d_ctx* ctx, const int32_t* idx, int nz, int n
 int exabm4d_i32_symbol_histogram_dev(exabm4d_ctx* ctx, const int32_t* idx, size_t n,
                                      uint64_t* hist_host);
 
-/* Chunk entropy coder (BASELINE.json config 5 "entropy encode"; DESIGN.md 3.11).  Replaces the
+/* Chunk entropy coder (BASELINE.json config 5 "entropy encode"; DESIGN.md 3.11 / 3.11b).  Replaces the
  * arithmetic behind `len(codec.encode(chunk))` in compute_cratio(img, codec, patch_shape=(64,64,64))
  * (utils/img_util.py:401-441: C-order chunks, edge chunks truncated) with the codec the reference
- * builds at evaluate.py:40 / scripts/evaluate_bm4dnet.py:140 -- Blosc(zstd, SHUFFLE): the same
- * byte shuffle (one plane per byte position of the element) in front of an entropy stage.  zstd is
- * third-party and absent, so the entropy stage is this repo's: static order-0 rANS per byte plane,
- * 64 interleaved states (the lanes of one wave), EXAC v1 stream (oracle/exac_codec.c states the
- * format; bytes are bit-identical to it).  typesize 2 = uint16 volumes, 4 = int32 quantisation
- * indices (exabm4d_dctq_forward_dev), mapped to unsigned by (v << 1) ^ (v >> 31).
+ * builds at evaluate.py:40 / scripts/evaluate_bm4dnet.py:140 -- Blosc(zstd, SHUFFLE).  zstd is
+ * third-party and absent, so the coder is this repo's; oracle/exac_codec.c states both formats and the
+ * kernels' bytes are bit-identical to it:
+ *   EXAC v2 (default): every element predicted from the voxel above and the voxel in the plane
+ *     before, zigzag residual -> 64-symbol alphabet + raw mantissa bits, 16 static tables per chunk
+ *     selected by the neighbours' residual magnitudes, 64 interleaved rANS states (the lanes of one
+ *     wave).  5.0 : 1 on the denoised bench volume where byte shuffle + zstd-5 gives 3.9 : 1.
+ *   EXAC v1 (exabm4d_set_option("codec_version", 1)): byte shuffle + static order-0 rANS per byte
+ *     plane (round 2's format; still decoded).
+ * typesize 2 = uint16 volumes, 4 = int32 quantisation indices (exabm4d_dctq_forward_dev; coded
+ * without prediction), mapped to unsigned by (v << 1) ^ (v >> 31).
  *
  * One call codes every chunk of a volume.  out (device, may be NULL: sizes only) receives the chunk
  * streams back to back, each starting at a multiple of 16 bytes (padding zeroed); out_capacity must
- * be >= exabm4d_codec_volume_bound().  offsets_dev[nchunks + 1] (device; may be NULL when out is
- * NULL) receives the start of every chunk's stream and the container length; sizes_dev[nchunks]
- * (device, may be NULL) the exact stream lengths, i.e. len(codec.encode(chunk)); totals_host[2]
- * (host, may be NULL; non-NULL makes the call synchronise) = { sum of the exact lengths, container
- * bytes }.  Chunks are numbered in (z, y, x) raster order. */
+ * be >= exabm4d_codec_volume_bound() (which covers either format).  offsets_dev[nchunks + 1] (device;
+ * may be NULL when out is NULL) receives the start of every chunk's stream and the container length;
+ * sizes_dev[nchunks] (device, may be NULL) the exact stream lengths, i.e. len(codec.encode(chunk));
+ * totals_host[2] (host, may be NULL; non-NULL makes the call synchronise) = { sum of the exact
+ * lengths, container bytes }.  Chunks are numbered in (z, y, x) raster order. */
 size_t exabm4d_codec_chunk_bound(size_t n_elems, int typesize);
 size_t exabm4d_codec_volume_bound(int typesize, int nz, int ny, int nx, int cz, int cy, int cx);
 int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int nz, int ny, int nx,
                              int cz, int cy, int cx, uint8_t* out, size_t out_capacity,
                              uint64_t* offsets_dev, uint32_t* sizes_dev, uint64_t* totals_host);
-/* Inverse: in + offsets_dev as produced above (or assembled by a host from stored streams) ->
- * vol[nz][ny][nx] of `typesize`-byte elements.  Synchronises; a malformed stream (bad magic,
- * wrong element count, truncated tables or words) gives EXABM4D_ERR_INVALID. */
-int exabm4d_codec_decode_dev(exabm4d_ctx* ctx, const uint8_t* in, const uint64_t* offsets_dev,
+/* Inverse: in (in_bytes bytes on the device) + offsets_dev as produced above (or assembled by a host
+ * from stored streams) -> vol[nz][ny][nx] of `typesize`-byte elements; the format version is read
+ * from the first chunk's header.  Synchronises.  A malformed container -- offsets that are not
+ * ascending, not 2-byte aligned or beyond in_bytes, bad magic, wrong element count or chunk shape,
+ * truncated tables or words, symbols outside the alphabet -- gives EXABM4D_ERR_INVALID and never
+ * reads outside [in, in + in_bytes). */
+int exabm4d_codec_decode_dev(exabm4d_ctx* ctx, const uint8_t* in, size_t in_bytes, const uint64_t* offsets_dev,
                              int typesize, int nz, int ny, int nx, int cz, int cy, int cx, void* vol);
 
 /* ---- background offset + quality metrics on device (SURVEY.md section 8 "next" row f-4) --------- */

@@ -263,3 +263,414 @@ int orc_exac_check_reciprocal(uint32_t x, uint32_t f) {
     }
     return q == x / f;
 }
+
+/* =================================================================================================
+ * EXAC v2 (round 3): predictive, context-modelled rANS -- still one static model
+ * per chunk, still 64 interleaved lanes and the word order of v1, so that every step stays a
+ * wave-wide operation on the GPU.  Why: v1's order-0 byte planes reached 3.3-3.4 : 1 on denoised
+ * volumes where byte shuffle + zstd-5 (the codec family the reference ships, evaluate.py:40)
+ * reaches 3.9 : 1; v2 reaches 5.0 : 1 on the same chunks.
+ *
+ * Chunk: n = ez * ey * ex elements in C order, element i <-> (z, y, x), lane(i) = i mod 64, a ROW is
+ * 64 consecutive elements.  All neighbours an element uses lie in EARLIER rows (the decoder
+ * recovers a whole row at once):
+ *   up tap    j_u = i - ku * ex,       ku = lane / ex + 1,        used iff y >= ku and ku * ex <= 8000
+ *   back tap  j_b = i - kb * ey * ex,  kb = lane / (ey * ex) + 1, used iff z >= kb and kb * ey * ex <= 8000
+ * (ku = kb = 1 whenever ex >= 64: the voxel above and the voxel in the plane before).
+ * Residual.  ts = 2 (uint16): P = (v[j_u] + v[j_b] + 1) >> 1 if both taps are used, the one tap's
+ * value if one is, 0 if none; r = (int16)(v - P), u = zigzag16(r).  ts = 4 (int32): u = zigzag32(v).
+ * Context.  mag(i) = min((u_i + 1) >> 1, 127); a = mag(j_u) + mag(j_b), or twice the one that is
+ * used, or 0; ctx = number of EDGES <= a, EDGES = {1,2,3,4,5,6,8,10,13,17,22,30,45,70,120}: 16 contexts.
+ * Symbol (64-symbol alphabet).  u < 32: s = u.  Otherwise w = u - 32, c = floor(log2((w >> 2) + 1)),
+ * s = 32 + c, followed by nb = 2 + c raw bits e = w - 4 (2^c - 1).
+ * Model.  cnt[ctx][s] over the chunk; F = max(1, floor(cnt * 4096 / total_ctx)) for cnt > 0; the
+ * difference to 4096 is added to the largest F (lowest s on ties) if that leaves it >= 1, else an
+ * excess is taken one count at a time from the symbol that currently has the largest F.
+ * Coder.  The v1 rANS (state in [2^15, 2^31), 12-bit probabilities, 16-bit words).  The raw bits go
+ * through the same state as up to three uniform steps of k = min(12, remaining) bits, low bits
+ * first: F = 4096 >> k, C = value << (12 - k).  Decoder, per row: (1) every lane decodes its
+ * symbol and renormalises; (2) for j = 0, 1, 2: the lanes with more than j raw steps decode step j
+ * and renormalise.  Within one renormalisation the words are taken in lane order; the encoder does
+ * the mirror image from the last row to the first, then appends the 64 final states.  When no
+ * context has more than one symbol and no symbol carries raw bits the stream has no words at all
+ * (nwords = 0; the decoder starts every lane at 2^15 and never renormalises).
+ *
+ *   0    'E' 'X' 2 ts
+ *   4    u32 n      8  u32 ey     12  u32 ex     16  u32 nwords
+ *   20   u64 present[16]   (bit s: symbol s occurs in the context)
+ *   148  u64 wide[16]      (bit s: F - 1 >= 256)
+ *   276  per context: (F - 1) & 255 of every present symbol ascending, then (F - 1) >> 8 of every
+ *        wide symbol ascending; zero-padded to an even total
+ *   ..   nwords little-endian 16-bit words
+ */
+#define EX2_NCTX 16
+#define EX2_NSYM 64
+#define EX2_LIMIT 8000u
+#define EX2_HDR 276
+
+static const uint8_t ex2_edges[15] = {1, 2, 3, 4, 5, 6, 8, 10, 13, 17, 22, 30, 45, 70, 120};
+
+static inline int ex2_ctx_of(uint32_t a) {
+    int c = 0;
+    while (c < 15 && a >= ex2_edges[c]) c++;
+    return c;
+}
+
+typedef struct {
+    size_t n, ey, ex, plane;
+} ex2_geom;
+
+/* taps of element i: returns flags (1: up used, 2: back used) and the tap indices */
+static inline int ex2_taps(const ex2_geom* g, size_t i, size_t* ju, size_t* jb) {
+    const size_t lane = i % EXAC_LANES;
+    const size_t x = i % g->ex, y = (i / g->ex) % g->ey, z = i / g->plane;
+    (void)x;
+    int flags = 0;
+    const size_t ku = lane / g->ex + 1, kb = lane / g->plane + 1;
+    if (y >= ku && ku * g->ex <= EX2_LIMIT) {
+        flags |= 1;
+        *ju = i - ku * g->ex;
+    }
+    if (z >= kb && kb * g->plane <= EX2_LIMIT) {
+        flags |= 2;
+        *jb = i - kb * g->plane;
+    }
+    return flags;
+}
+
+static inline uint32_t ex2_mag(uint32_t u) {
+    const uint32_t m = (u >> 1) + (u & 1u);
+    return m < 127u ? m : 127u;
+}
+
+static inline uint32_t ex2_activity(int flags, const uint8_t* mag, size_t ju, size_t jb) {
+    if (flags == 3) return (uint32_t)mag[ju] + mag[jb];
+    if (flags == 1) return 2u * mag[ju];
+    if (flags == 2) return 2u * mag[jb];
+    return 0;
+}
+
+/* u -> symbol, number of raw bits, raw value */
+static inline uint32_t ex2_symbol(uint32_t u, uint32_t* nb, uint32_t* e) {
+    if (u < 32u) {
+        *nb = 0;
+        *e = 0;
+        return u;
+    }
+    const uint32_t w = u - 32u, t = (w >> 2) + 1u;
+    uint32_t c = 0;
+    while ((t >> (c + 1)) != 0) c++;
+    *nb = 2u + c;
+    *e = w - (((1u << c) - 1u) << 2);
+    return 32u + c;
+}
+
+void orc_exac2_normalize(const uint32_t cnt[EX2_NSYM], uint16_t F[EX2_NSYM]) {
+    uint64_t tot = 0;
+    for (int s = 0; s < EX2_NSYM; s++) tot += cnt[s];
+    memset(F, 0, EX2_NSYM * sizeof(uint16_t));
+    if (!tot) return;
+    uint32_t sum = 0;
+    for (int s = 0; s < EX2_NSYM; s++)
+        if (cnt[s]) {
+            uint64_t f = ((uint64_t)cnt[s] * EXAC_M) / tot;
+            F[s] = (uint16_t)(f < 1 ? 1 : f);
+            sum += F[s];
+        }
+    int best = 0;
+    for (int s = 1; s < EX2_NSYM; s++)
+        if (F[s] > F[best]) best = s;
+    const int32_t diff = (int32_t)EXAC_M - (int32_t)sum;
+    if ((int32_t)F[best] + diff >= 1) {
+        F[best] = (uint16_t)((int32_t)F[best] + diff);
+        return;
+    }
+    while (sum > EXAC_M) {
+        best = 0;
+        for (int s = 1; s < EX2_NSYM; s++)
+            if (F[s] > F[best]) best = s;
+        F[best]--;
+        sum--;
+    }
+}
+
+size_t orc_exac2_bound(size_t n, int ts) {
+    /* header + bitmaps, 16 x 64 x 2 table bytes, and per element one symbol word plus its raw
+     * steps (16 or 32 bits, each step may renormalise once), plus the final states */
+    return EX2_HDR + (size_t)EX2_NCTX * EX2_NSYM * 2 + 2 * ((size_t)(ts == 2 ? 3 : 4) * n + 128);
+}
+
+static inline void ex2_put(uint8_t* w, uint32_t* nwords, uint32_t x) {
+    const uint16_t lo = (uint16_t)(x & 0xFFFFu);
+    memcpy(w + 2 * (size_t)*nwords, &lo, 2);
+    (*nwords)++;
+}
+
+/* Returns the stream length; the chunk's shape is ez x ey x ex with ez = n / (ey * ex). */
+size_t orc_exac2_encode(const void* src, size_t n, size_t ey, size_t ex, int ts, uint8_t* out) {
+    if (ey < 1 || ex < 1 || n % (ey * ex) != 0) return 0;
+    const ex2_geom g = {n, ey, ex, ey * ex};
+    const size_t rows = (n + EXAC_LANES - 1) / EXAC_LANES;
+    uint32_t* u = malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint8_t* mag = malloc(n ? n : 1);
+    uint8_t* ctx = malloc(n ? n : 1);
+    for (size_t i = 0; i < n; i++) {
+        size_t ju = 0, jb = 0;
+        const int fl = ex2_taps(&g, i, &ju, &jb);
+        if (ts == 2) {
+            const uint16_t* v = src;
+            uint32_t P = 0;
+            if (fl == 3) P = ((uint32_t)v[ju] + v[jb] + 1u) >> 1;
+            else if (fl == 1) P = v[ju];
+            else if (fl == 2) P = v[jb];
+            const int16_t r = (int16_t)(uint16_t)(v[i] - P);
+            u[i] = (uint16_t)(((uint16_t)r << 1) ^ (uint16_t)(r >> 15));
+        } else {
+            const int32_t v = ((const int32_t*)src)[i];
+            u[i] = ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+        }
+        mag[i] = (uint8_t)ex2_mag(u[i]);
+        ctx[i] = (uint8_t)ex2_ctx_of(ex2_activity(fl, mag, ju, jb));
+    }
+    uint32_t cnt[EX2_NCTX][EX2_NSYM];
+    memset(cnt, 0, sizeof(cnt));
+    int coded = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t nb, e;
+        cnt[ctx[i]][ex2_symbol(u[i], &nb, &e)]++;
+        if (nb) coded = 1;
+    }
+    uint16_t F[EX2_NCTX][EX2_NSYM];
+    uint32_t C[EX2_NCTX][EX2_NSYM];
+    uint64_t present[EX2_NCTX], wide[EX2_NCTX];
+    uint8_t* tab = out + EX2_HDR;
+    for (int c = 0; c < EX2_NCTX; c++) {
+        orc_exac2_normalize(cnt[c], F[c]);
+        present[c] = wide[c] = 0;
+        uint32_t acc = 0, np = 0;
+        for (int s = 0; s < EX2_NSYM; s++) {
+            C[c][s] = acc;
+            acc += F[c][s];
+            if (F[c][s]) {
+                present[c] |= 1ull << s;
+                np++;
+                if (F[c][s] - 1u >= 256u) wide[c] |= 1ull << s;
+            }
+        }
+        if (np > 1) coded = 1;
+        for (int s = 0; s < EX2_NSYM; s++)
+            if (F[c][s]) *tab++ = (uint8_t)((F[c][s] - 1u) & 255u);
+        for (int s = 0; s < EX2_NSYM; s++)
+            if (wide[c] >> s & 1ull) *tab++ = (uint8_t)((F[c][s] - 1u) >> 8);
+    }
+    if ((size_t)(tab - out) & 1u) *tab++ = 0;
+    out[0] = 'E';
+    out[1] = 'X';
+    out[2] = 2;
+    out[3] = (uint8_t)ts;
+    uint32_t h[3] = {(uint32_t)n, (uint32_t)ey, (uint32_t)ex};
+    memcpy(out + 4, h, 12);
+    memcpy(out + 20, present, sizeof(present));
+    memcpy(out + 148, wide, sizeof(wide));
+    uint8_t* w = tab;
+    uint32_t nwords = 0;
+    if (coded) {
+        uint32_t x[EXAC_LANES];
+        for (int l = 0; l < EXAC_LANES; l++) x[l] = EXAC_L;
+        for (size_t r = rows; r-- > 0;) {
+            uint32_t sym[EXAC_LANES], nb[EXAC_LANES], e[EXAC_LANES];
+            int act[EXAC_LANES];
+            for (int l = 0; l < EXAC_LANES; l++) {
+                const size_t i = r * EXAC_LANES + (size_t)l;
+                act[l] = i < n;
+                sym[l] = nb[l] = e[l] = 0;
+                if (act[l]) sym[l] = ex2_symbol(u[i], &nb[l], &e[l]);
+            }
+            for (int j = 2; j >= 0; j--)
+                for (int l = 0; l < EXAC_LANES; l++) {
+                    if (!act[l] || nb[l] <= 12u * (uint32_t)j) continue;
+                    const uint32_t k = nb[l] - 12u * j < 12u ? nb[l] - 12u * j : 12u;
+                    const uint32_t f = EXAC_M >> k, val = (e[l] >> (12 * j)) & ((1u << k) - 1u);
+                    if (x[l] >= (f << 19)) {
+                        ex2_put(w, &nwords, x[l]);
+                        x[l] >>= 16;
+                    }
+                    x[l] = ((x[l] / f) << EXAC_BITS) + (x[l] % f) + val * f;
+                }
+            for (int l = 0; l < EXAC_LANES; l++) {
+                if (!act[l]) continue;
+                const size_t i = r * EXAC_LANES + (size_t)l;
+                const uint32_t f = F[ctx[i]][sym[l]];
+                if (x[l] >= (f << 19)) {
+                    ex2_put(w, &nwords, x[l]);
+                    x[l] >>= 16;
+                }
+                x[l] = ((x[l] / f) << EXAC_BITS) + (x[l] % f) + C[ctx[i]][sym[l]];
+            }
+        }
+        for (int l = 0; l < EXAC_LANES; l++) {
+            ex2_put(w, &nwords, x[l]);
+            ex2_put(w, &nwords, x[l] >> 16);
+        }
+    }
+    memcpy(out + 16, &nwords, 4);
+    free(u);
+    free(mag);
+    free(ctx);
+    return (size_t)(w - out) + 2 * (size_t)nwords;
+}
+
+/* Decodes one v2 chunk stream (n and ts are checked against the header; the shape comes from the
+ * header).  Returns the number of bytes consumed, or 0 for a malformed stream. */
+size_t orc_exac2_decode(const uint8_t* in, size_t in_bytes, size_t n, int ts, void* dst) {
+    if (in_bytes < EX2_HDR || in[0] != 'E' || in[1] != 'X' || in[2] != 2 || in[3] != ts) return 0;
+    uint32_t h[4];
+    memcpy(h, in + 4, 16);
+    if (h[0] != n || h[1] < 1 || h[2] < 1 || (uint64_t)h[1] * h[2] > (n ? n : 1) ||
+        n % ((size_t)h[1] * h[2]) != 0)
+        return 0;
+    const ex2_geom g = {n, h[1], h[2], (size_t)h[1] * h[2]};
+    const uint32_t nwords = h[3];
+    uint64_t present[EX2_NCTX], wide[EX2_NCTX];
+    memcpy(present, in + 20, sizeof(present));
+    memcpy(wide, in + 148, sizeof(wide));
+    uint16_t F[EX2_NCTX][EX2_NSYM];
+    uint32_t C[EX2_NCTX][EX2_NSYM + 1];
+    const uint8_t* tab = in + EX2_HDR;
+    for (int c = 0; c < EX2_NCTX; c++) {
+        if (wide[c] & ~present[c]) return 0;
+        const size_t np = (size_t)__builtin_popcountll(present[c]), nw = (size_t)__builtin_popcountll(wide[c]);
+        if ((size_t)(tab - in) + np + nw > in_bytes) return 0;
+        uint32_t acc = 0;
+        size_t a = 0, b = 0;
+        for (int s = 0; s < EX2_NSYM; s++) {
+            uint32_t f = 0;
+            if (present[c] >> s & 1ull) {
+                f = tab[a++];
+                if (wide[c] >> s & 1ull) f |= (uint32_t)tab[np + b++] << 8;
+                f += 1u;
+            }
+            F[c][s] = (uint16_t)f;
+            C[c][s] = acc;
+            acc += f;
+        }
+        C[c][EX2_NSYM] = acc;
+        if (np && acc != EXAC_M) return 0;
+        tab += np + nw;
+    }
+    if ((size_t)(tab - in) & 1u) tab++;
+    const uint8_t* w = tab;
+    if ((size_t)(w - in) + 2 * (size_t)nwords > in_bytes) return 0;
+    if (nwords != 0 && nwords < 128) return 0;
+    const size_t rows = (n + EXAC_LANES - 1) / EXAC_LANES;
+    uint8_t* mag = malloc(n ? n : 1);
+    uint32_t x[EXAC_LANES];
+    size_t cursor = nwords ? (size_t)nwords - 128 : 0;
+    for (int l = 0; l < EXAC_LANES; l++) {
+        x[l] = EXAC_L;
+        if (nwords) {
+            uint16_t lo, hi;
+            memcpy(&lo, w + 2 * (cursor + 2 * (size_t)l), 2);
+            memcpy(&hi, w + 2 * (cursor + 2 * (size_t)l + 1), 2);
+            x[l] = (uint32_t)lo | ((uint32_t)hi << 16);
+        }
+    }
+    int ok = 1;
+    for (size_t r = 0; r < rows && ok; r++) {
+        uint32_t sym[EXAC_LANES], nb[EXAC_LANES], e[EXAC_LANES], P[EXAC_LANES];
+        int act[EXAC_LANES], need[EXAC_LANES];
+        /* (1) symbols */
+        int k = 0;
+        for (int l = 0; l < EXAC_LANES; l++) {
+            const size_t i = r * EXAC_LANES + (size_t)l;
+            act[l] = i < n;
+            need[l] = 0;
+            sym[l] = nb[l] = e[l] = P[l] = 0;
+            if (!act[l]) continue;
+            size_t ju = 0, jb = 0;
+            const int fl = ex2_taps(&g, i, &ju, &jb);
+            const int c = ex2_ctx_of(ex2_activity(fl, mag, ju, jb));
+            if (ts == 2) {
+                const uint16_t* v = dst;
+                if (fl == 3) P[l] = ((uint32_t)v[ju] + v[jb] + 1u) >> 1;
+                else if (fl == 1) P[l] = v[ju];
+                else if (fl == 2) P[l] = v[jb];
+            }
+            if (!present[c]) {
+                ok = 0;
+                break;
+            }
+            const uint32_t slot = x[l] & (EXAC_M - 1);
+            uint32_t s = 0;
+            while (C[c][s + 1] <= slot) s++;
+            sym[l] = s;
+            x[l] = F[c][s] * (x[l] >> EXAC_BITS) + slot - C[c][s];
+            nb[l] = s < 32u ? 0u : s - 30u;
+            if (x[l] < EXAC_L) {
+                need[l] = 1;
+                k++;
+            }
+        }
+        if (!ok) break;
+        for (int j = -1; j < 3 && ok; j++) {
+            if (j >= 0) {
+                k = 0;
+                for (int l = 0; l < EXAC_LANES; l++) {
+                    need[l] = 0;
+                    if (!act[l] || nb[l] <= 12u * (uint32_t)j) continue;
+                    const uint32_t kk = nb[l] - 12u * j < 12u ? nb[l] - 12u * j : 12u;
+                    const uint32_t f = EXAC_M >> kk, slot = x[l] & (EXAC_M - 1);
+                    e[l] |= (slot >> (12 - kk)) << (12 * j);
+                    x[l] = f * (x[l] >> EXAC_BITS) + (slot & (f - 1u));
+                    if (x[l] < EXAC_L) {
+                        need[l] = 1;
+                        k++;
+                    }
+                }
+            }
+            if ((size_t)k > cursor) {
+                ok = 0;
+                break;
+            }
+            size_t pos = cursor - (size_t)k;
+            cursor = pos;
+            for (int l = 0; l < EXAC_LANES; l++)
+                if (need[l]) {
+                    uint16_t v;
+                    memcpy(&v, w + 2 * pos, 2);
+                    pos++;
+                    x[l] = (x[l] << 16) | v;
+                }
+        }
+        /* (3) values */
+        for (int l = 0; l < EXAC_LANES && ok; l++) {
+            if (!act[l]) continue;
+            const size_t i = r * EXAC_LANES + (size_t)l;
+            uint32_t u = sym[l];
+            if (sym[l] >= 32u) {
+                const uint32_t c = sym[l] - 32u;
+                const uint64_t wide_u = 32ull + ((((uint64_t)1 << c) - 1ull) << 2) + e[l];
+                if (c > 29u || (ts == 2 && c > 13u) || wide_u > 0xFFFFFFFFull) {
+                    ok = 0;
+                    break;
+                }
+                u = (uint32_t)wide_u;
+            }
+            mag[i] = (uint8_t)ex2_mag(u);
+            if (ts == 2) {
+                if (u > 0xFFFFu) {
+                    ok = 0;
+                    break;
+                }
+                const uint16_t zz = (uint16_t)u;
+                const uint16_t r16 = (uint16_t)((zz >> 1) ^ (uint16_t)(0u - (zz & 1u)));
+                ((uint16_t*)dst)[i] = (uint16_t)(P[l] + r16);
+            } else {
+                ((int32_t*)dst)[i] = (int32_t)((u >> 1) ^ (0u - (u & 1u)));
+            }
+        }
+    }
+    free(mag);
+    if (!ok) return 0;
+    return (size_t)(w - in) + 2 * (size_t)nwords;
+}

@@ -43,7 +43,15 @@ def test_default_line_has_the_contract_keys():
     for phase in ("blockmatch_ht", "stage_ht", "blockmatch_wie", "stage_wie", "encode_u16", "dct_quantise",
                   "encode_idx"):
         assert d["phase_ms"][phase] > 0, phase
-    assert d["encoded"]["cratio_denoised"] > d["encoded"]["cratio_raw"] > 1.0
+    e = d["encoded"]
+    assert e["cratio_denoised"] > e["cratio_raw"] > 1.0
+    if e.get("cratio_zstd5_shuffle") is not None:             # libzstd present: the reference's codec family
+        assert e["cratio_denoised_same_chunks"] >= e["cratio_zstd5_shuffle"]
+    # PSNR vs the CPU port on the same 256^3 volume (BASELINE.json's metric names it): < 0.01 dB apart
+    p = d["psnr"]
+    assert abs(p["delta_db"]) < 0.01 and p["max_abs_u16"] <= 1 and p["frac_differing"] < 5e-3
+    assert p["gpu_vs_clean"] > p["noisy_vs_clean"] + 10.0
+    assert c["encode"]["exac_v2_port"]["cratio"] > 3.0
 
 
 @pytest.mark.gpu

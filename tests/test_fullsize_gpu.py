@@ -157,7 +157,8 @@ def test_config5_chain_at_1024(full1024, ctx):
     """BASELINE.json configs[4] at full size: denoised volume -> (a) lossless chunk coder, decode
     == input; (b) 8^3 block DCT quantiser -> chunk coder on the indices -> decode == indices ->
     dequantise: error bounded by the step.  Three chunk streams are compared with the oracle's
-    bytes; the coded sizes sit between the order-0 entropy floor and 1.01 x floor."""
+    bytes (EXAC v2, the default); the coded sizes lie below the order-0 entropy of the byte planes
+    (v1's floor), i.e. the context model pays."""
     from aind_exaspim_image_compression import _native
     from oracle import codec_oracle as co
     vol, full = full1024
@@ -181,7 +182,7 @@ def test_config5_chain_at_1024(full1024, ctx):
     # (a) lossless leg on the denoised uint16 volume, 64^3 chunks
     t_out, t_off, t_sz, exact = encode(t_full, 2, shape, (64, 64, 64))
     t_back = torch.empty_like(t_full)
-    ctx.codec_decode(t_out, t_off, 2, shape, (64, 64, 64), t_back)
+    ctx.codec_decode(t_out, t_out.numel(), t_off, 2, shape, (64, 64, 64), t_back)
     assert torch.equal(t_back, t_full)
     off, sz = t_off.cpu().numpy(), t_sz.cpu().numpy()
     for c in (0, 1234, 4095):
@@ -190,9 +191,8 @@ def test_config5_chain_at_1024(full1024, ctx):
         want = co.encode(chunk)
         got = t_out[int(off[c]):int(off[c]) + int(sz[c])].cpu().numpy().tobytes()
         assert got == want, f"chunk {c}"
-        floor = co.plane_entropy_bytes(chunk)
-        assert floor <= len(want) <= 1.01 * floor + 16 + 2 * (32 + 512 + 256)
-    assert 2.5 < 2.0 * n ** 3 / exact < 20.0                 # denoised data compress; raw ~2
+        assert len(want) < co.plane_entropy_bytes(chunk)     # below what any order-0 byte-plane coder can reach
+    assert 4.0 < 2.0 * n ** 3 / exact < 20.0                 # denoised data compress; raw ~2
     del t_out, t_back
     # (b) config 5's lossy leg
     q = 8.0
@@ -202,9 +202,9 @@ def test_config5_chain_at_1024(full1024, ctx):
     ishape, ichunk = (nblk, 8, 64), (512, 8, 64)
     t_out, t_off, t_sz, exact_i = encode(t_idx, 4, ishape, ichunk)
     t_iback = torch.empty_like(t_idx)
-    ctx.codec_decode(t_out, t_off, 4, ishape, ichunk, t_iback)
+    ctx.codec_decode(t_out, t_out.numel(), t_off, 4, ishape, ichunk, t_iback)
     assert torch.equal(t_iback, t_idx)
-    first = t_idx[:1 << 18].cpu().numpy()
+    first = t_idx[:1 << 18].cpu().numpy().reshape(ichunk)
     o0, s0 = int(t_off[0]), int(t_sz[0])
     assert t_out[o0:o0 + s0].cpu().numpy().tobytes() == co.encode(first)
     t_rec = torch.empty_like(t_full)

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from aind_exaspim_image_compression import _native  # noqa: E402
-from aind_exaspim_image_compression.utils.chunk_codec import ShuffleRansCodec  # noqa: E402
+from aind_exaspim_image_compression.utils.chunk_codec import ExacCodec  # noqa: E402
 from oracle import bm4d_oracle as O  # noqa: E402
 from oracle import codec_oracle as C  # noqa: E402
 from util import synth_volume  # noqa: E402
@@ -59,7 +59,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     max_edge = int(sys.argv[3]) if len(sys.argv) > 3 else 72
     ctx = _native.context(0)
-    codec = ShuffleRansCodec()
+    codec = ExacCodec()
     t0, it = time.time(), 0
     while time.time() - t0 < budget:
         it += 1
