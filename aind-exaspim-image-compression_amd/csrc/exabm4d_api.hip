@@ -991,7 +991,8 @@ int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, in
     unsigned long long *offsets, *totals;
     int rc = codec_aux(ctx, g.nchunks, sizes, offsets, totals, status);
     if (rc) return rc;
-    rc = ensure_scratch(ctx, (size_t)g.nchunks * g.slot_bytes);
+    rc = ensure_scratch(ctx, (((size_t)g.nchunks * g.slot_bytes + 255) & ~(size_t)255) +
+                                 (g.version == 2 ? codec2_work_bytes(g) : 0));
     if (rc) return rc;
     if (sizes_dev) sizes = sizes_dev;
     if (offsets_dev) offsets = reinterpret_cast<unsigned long long*>(offsets_dev);

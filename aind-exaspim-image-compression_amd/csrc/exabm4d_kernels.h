@@ -98,6 +98,7 @@ struct CodecGeom {
     size_t slot_hdr;         // scratch slot of one chunk: header + tables ...
     size_t slot_plane;       // ... then `ts` stream regions of this many bytes
     size_t slot_bytes;
+    size_t chunk_elems;      // cz * cy * cx: stride of a chunk in the v2 encoder's code scratch
     int version;             // stream format: 1 = byte planes, 2 = predictive context model (3.11b)
 };
 int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, CodecGeom& g, int version = 2);
@@ -105,6 +106,7 @@ size_t codec_chunk_bound(size_t n, int ts);
 size_t codec_volume_bound(const CodecGeom& g);
 void codec_fill_rcp_table(uint32_t* tab /* [4097][2]: reciprocal, shift */);
 // sizes[nchunks], offsets[nchunks + 1], totals[2] are device arrays; out == nullptr skips the packing
+// slots: nchunks * g.slot_bytes of scratch, followed (v2) by codec2_work_bytes(g) more
 hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
                               uint32_t* sizes, unsigned long long* offsets, unsigned long long* totals,
                               uint8_t* out, hipStream_t s);
@@ -113,9 +115,10 @@ hipError_t launch_rans_decode(const uint8_t* in, size_t in_bytes, const unsigned
 // EXAC v2 (rans2_kernels.hip); stage 0: code every chunk into its slot, stage 1: pack the slots
 size_t codec2_chunk_bound(size_t n, int ts);
 void codec2_slot_layout(size_t chunk_elems, int ts, size_t& slot_hdr, size_t& slot_bytes);
+size_t codec2_work_bytes(const CodecGeom& g);      // encoder scratch behind the slots: codes + histograms
 hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
-                               uint32_t* sizes, uint8_t* out, const unsigned long long* offsets, int stage,
-                               hipStream_t s);
+                               uint8_t* work, uint32_t* sizes, uint8_t* out, const unsigned long long* offsets,
+                               int stage, hipStream_t s);
 hipError_t launch_rans2_decode(const uint8_t* in, size_t in_bytes, const unsigned long long* offsets,
                                const CodecGeom& g, void* vol, uint32_t* status, hipStream_t s);
 

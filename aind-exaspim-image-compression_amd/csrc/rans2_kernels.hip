@@ -145,80 +145,194 @@ __device__ __forceinline__ void renorm_put(uint32_t& x, uint32_t f, bool act, ui
 }  // namespace
 
 // ---- encode ---------------------------------------------------------------------------------------------------
+// Two kernels.  (1) rans2_model_kernel: every element's (context, symbol, raw bits) -- embarrassingly
+// parallel, many workgroups per chunk -- written as one packed code per element into scratch, and
+// counted into the chunk's 16 x 64 histogram (LDS per workgroup, then global atomics on the non-zero
+// bins).  (2) rans2_code_kernel: one wave per chunk turns the histograms into tables (lane = symbol),
+// writes header + tables into the chunk's slot and walks the codes from the last row to the first;
+// that loop is the serial rANS chain and touches nothing but the codes and an 8 KB table in LDS.
+// Codes: TS = 2: u32 = ctx | s << 4 | e << 10 (e < 2^15).  TS = 4: u16 = ctx | s << 4; the coder
+// takes the raw bits from the element itself (zigzag of the value, no taps needed).
 // Slot (scratch, per chunk): [0, 276) header, [276, 276 + 2048) table bytes, u32 table length at
 // SLOT2_TABLEN, 16-bit words from g.slot_hdr.
+constexpr int MODEL_WAVES = 4;            // waves per workgroup of the model kernel
+constexpr int MODEL_ROWS = 512;           // rows of 64 elements per workgroup (8 planes of a 64^3 chunk)
+
 template <int TS>
-__global__ __launch_bounds__(64) void rans2_encode_kernel(const void* __restrict__ vol, CodecGeom g,
-                                                          const uint2* __restrict__ rcp_tab,
-                                                          uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes) {
+__device__ __forceinline__ void put_code(void* __restrict__ codes, size_t at, const Model& m) {
+    if (TS == 2)
+        static_cast<uint32_t*>(codes)[at] = m.ctx | (m.s << 4) | (m.e << 10);
+    else
+        static_cast<uint16_t*>(codes)[at] = (uint16_t)(m.ctx | (m.s << 4));
+}
+
+// Generic form: any chunk shape, every element models itself (three residuals for uint16; for int32
+// the residual is the zigzag value, so this is also the fast form of that kind).
+template <int TS>
+__global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_kernel(const void* __restrict__ vol, CodecGeom g,
+                                                                        int blocks_per_chunk,
+                                                                        void* __restrict__ codes,
+                                                                        uint32_t* __restrict__ ghist) {
     constexpr int NC = EXABM4D_ENC2_NC, RB = EXABM4D_ENC2_RB;
     __shared__ uint32_t hist[NCTX * NSYM * NC];
+    const int c = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t n = b.n;
+    const uint32_t rows = (n + 63u) >> 6;
+    const uint32_t r_lo = (uint32_t)blk * MODEL_ROWS, r_hi = min(rows, r_lo + (uint32_t)MODEL_ROWS);
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM * NC); j += 64 * MODEL_WAVES) hist[j] = 0u;
+    __syncthreads();
+    if (r_lo < r_hi) {
+        const bool fast = (b.ex & 63) == 0;
+        Taps<TS> t;
+        t.ex = (uint32_t)b.ex;
+        t.ey = (uint32_t)b.ey;
+        t.plane = t.ex * t.ey;
+        t.n = n;
+        t.sy = (size_t)g.nx;
+        t.sz = (size_t)g.nx * g.ny;
+        t.wide_x = t.ex >= 64u;
+        t.wide_p = t.plane >= 64u;
+        RowCursor rc;
+        rc.rpx = (uint32_t)b.ex >> 6;
+        rc.ey = (uint32_t)b.ey;
+        const size_t cbase = (size_t)c * g.chunk_elems;
+        for (uint32_t r0 = r_lo + wave * RB; r0 < r_hi; r0 += MODEL_WAVES * RB) {
+            if (fast) rc.seek(r0);
+            Model m[RB];
+            bool act[RB];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const uint32_t r = r0 + k, i = r * 64u + lane;
+                act[k] = r < r_hi && i < n;
+                RowPos p;
+                if (fast) {
+                    p.x = rc.xr * 64u + lane;
+                    p.y = rc.y;
+                    p.z = rc.z;
+                    if (r + 1 < r_hi) rc.next();
+                } else {
+                    p = pos_of(min(i, n - 1u), t.ex, t.ey);
+                }
+                m[k] = model_of<TS>(vol, b.base, t, i, p, act[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++)
+                if (act[k]) {
+                    atomicAdd(&hist[(m[k].ctx * NSYM + m[k].s) * NC + (lane & (NC - 1))], 1u);
+                    put_code<TS>(codes, cbase + (size_t)(r0 + k) * 64u + lane, m[k]);
+                }
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = ghist + (size_t)c * (NCTX * NSYM);
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM); j += 64 * MODEL_WAVES) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) v += hist[j * NC + k];
+        if (v) atomicAdd(&gh[j], v);
+    }
+}
+
+// uint16 chunks whose rows are x-rows of the volume (ex a multiple of 64) and whose planes hold at
+// most 4096 elements -- the reference's 64^3 chunks: a workgroup walks MODEL_ROWS / (rows per plane)
+// planes, computes every residual ONCE (a wave keeps its rows' residuals in registers), publishes the
+// magnitudes of a plane in LDS, and reads the contexts' two magnitudes from there.
+__global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_planes_kernel(const uint16_t* __restrict__ vol,
+                                                                               CodecGeom g, int blocks_per_chunk,
+                                                                               int planes_per_block,
+                                                                               uint32_t* __restrict__ codes,
+                                                                               uint32_t* __restrict__ ghist) {
+    constexpr int NC = EXABM4D_ENC2_NC, RPW = 16;            // rows of a plane per wave: <= 64 / MODEL_WAVES
+    __shared__ uint32_t hist[NCTX * NSYM * NC];
+    __shared__ uint8_t mags[2][4096];
+    const int c = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t ex = (uint32_t)b.ex, ey = (uint32_t)b.ey, rpx = ex >> 6, rp = ey * rpx;   // rows per plane
+    const uint32_t ez = b.n / (ex * ey);
+    const uint32_t z_lo = (uint32_t)blk * (uint32_t)planes_per_block, z_hi = min(ez, z_lo + (uint32_t)planes_per_block);
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM * NC); j += 64 * MODEL_WAVES) hist[j] = 0u;
+    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * g.ny;
+    const uint16_t* v16 = vol + b.base;
+    const size_t cbase = (size_t)c * g.chunk_elems;
+
+    // zigzag residual of row q (y = q / rpx, segment q % rpx) of plane z, this lane's element
+    auto resid = [&](uint32_t z, uint32_t q) -> uint32_t {
+        const uint32_t y = q / rpx, xr = q - y * rpx;
+        const size_t off = (size_t)z * sz + (size_t)y * sy + xr * 64u + lane;
+        const uint32_t v = v16[off];
+        const bool U = y > 0u, B = z > 0u;
+        const uint32_t vu = v16[U ? off - sy : off], vb = v16[B ? off - sz : off];
+        const uint32_t pred = U && B ? (vu + vb + 1u) >> 1 : (U ? vu : (B ? vb : 0u));
+        const int32_t r = (int32_t)(int16_t)(uint16_t)(v - pred);
+        return (uint32_t)(((r << 1) ^ (r >> 15)) & 0xFFFF);
+    };
+    if (z_lo < z_hi && z_lo > 0u) {           // magnitudes of the plane before the block
+        for (uint32_t q = wave; q < rp; q += MODEL_WAVES) mags[(z_lo - 1u) & 1u][q * 64u + lane] = (uint8_t)mag_of(resid(z_lo - 1u, q));
+    }
+    __syncthreads();
+    for (uint32_t z = z_lo; z < z_hi; z++) {
+        uint32_t u[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const uint32_t q = wave + (uint32_t)k * MODEL_WAVES;
+            u[k] = q < rp ? resid(z, q) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const uint32_t q = wave + (uint32_t)k * MODEL_WAVES;
+            if (q < rp) mags[z & 1u][q * 64u + lane] = (uint8_t)mag_of(u[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const uint32_t q = wave + (uint32_t)k * MODEL_WAVES;
+            if (q >= rp) continue;
+            const bool U = q >= rpx, B = z > 0u;
+            const uint32_t mu = U ? mags[z & 1u][(q - rpx) * 64u + lane] : 0u;
+            const uint32_t mb = B ? mags[(z - 1u) & 1u][q * 64u + lane] : 0u;
+            const uint32_t a = U && B ? mu + mb : (U ? 2u * mu : (B ? 2u * mb : 0u));
+            Model m;
+            symbol_of(u[k], m.s, m.nb, m.e);
+            m.ctx = ctx_of_activity(a);
+            atomicAdd(&hist[(m.ctx * NSYM + m.s) * NC + (lane & (NC - 1))], 1u);
+            codes[cbase + ((size_t)z * rp + q) * 64u + lane] = m.ctx | (m.s << 4) | (m.e << 10);
+        }
+        __syncthreads();
+    }
+    uint32_t* gh = ghist + (size_t)c * (NCTX * NSYM);
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM); j += 64 * MODEL_WAVES) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < NC; k++) v += hist[j * NC + k];
+        if (v) atomicAdd(&gh[j], v);
+    }
+}
+
+template <int TS>
+__global__ __launch_bounds__(64) void rans2_code_kernel(const void* __restrict__ vol, CodecGeom g,
+                                                        const uint2* __restrict__ rcp_tab,
+                                                        const void* __restrict__ codes,
+                                                        const uint32_t* __restrict__ ghist,
+                                                        uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes) {
+    constexpr int RB = 8;
     __shared__ uint2 etab[NCTX * NSYM];
     const int c = blockIdx.x;
     const uint32_t lane = lane_id();
     const ChunkBox b = chunk_box(g, c);
     const uint32_t n = b.n;
     const uint32_t rows = (n + 63u) >> 6;
-    const bool fast = (b.ex & 63) == 0;
-    Taps<TS> t;
-    t.ex = (uint32_t)b.ex;
-    t.ey = (uint32_t)b.ey;
-    t.plane = t.ex * t.ey;
-    t.n = n;
-    t.sy = (size_t)g.nx;
-    t.sz = (size_t)g.nx * g.ny;
-    t.wide_x = t.ex >= 64u;
-    t.wide_p = t.plane >= 64u;
-    RowCursor rc;
-    rc.rpx = (uint32_t)b.ex >> 6;
-    rc.ey = (uint32_t)b.ey;
     uint8_t* slot = slots + (size_t)c * g.slot_bytes;
-
-#pragma unroll
-    for (int j = 0; j < NCTX * NC; j++) hist[64 * j + lane] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    auto row_pos = [&](uint32_t r) -> RowPos {
-        RowPos p;
-        if (fast) {
-            p.x = rc.xr * 64u + lane;
-            p.y = rc.y;
-            p.z = rc.z;
-        } else {
-            p = pos_of(min(r * 64u + lane, n - 1u), t.ex, t.ey);
-        }
-        return p;
-    };
-
-    // -- pass 1: (context, symbol) histograms ------------------------------------------------------------
-    rc.xr = rc.y = rc.z = 0;
-    for (uint32_t r0 = 0; r0 < rows; r0 += RB) {
-        Model m[RB];
-        bool act[RB];
-#pragma unroll
-        for (int k = 0; k < RB; k++) {
-            const uint32_t r = r0 + k, i = r * 64u + lane;
-            act[k] = r < rows && i < n;
-            const RowPos p = row_pos(r);
-            m[k] = model_of<TS>(vol, b.base, t, i, p, act[k]);
-            if (fast && r < rows) rc.next();
-        }
-#pragma unroll
-        for (int k = 0; k < RB; k++)
-            if (act[k]) atomicAdd(&hist[(m[k].ctx * NSYM + m[k].s) * NC + (lane & (NC - 1))], 1u);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
 
     // -- tables: lane = symbol ----------------------------------------------------------------------------------
     uint32_t toff = 0;
     bool coded = false;
     uint8_t* tab = slot + HDR2;
+    const uint32_t* gh = ghist + (size_t)c * (NCTX * NSYM);
     for (int q = 0; q < NCTX; q++) {
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int k = 0; k < NC; k++) cnt += hist[(q * NSYM + lane) * NC + k];
+        const uint32_t cnt = gh[q * NSYM + lane];
         const uint32_t tot = wave_sum(cnt);
         uint32_t F = 0;
         if (cnt) {
@@ -261,7 +375,7 @@ __global__ __launch_bounds__(64) void rans2_encode_kernel(const void* __restrict
             e.x = F | (bias << 13) | (rs.y << 26);
             e.y = rs.x;
         }
-        etab[q * NSYM + lane] = e;
+        etab[lane * NCTX + q] = e;              // indexed by the low ten bits of a code: ctx | s << 4
     }
     if (toff & 1u) {
         if (lane == 0) tab[toff] = 0;
@@ -270,37 +384,59 @@ __global__ __launch_bounds__(64) void rans2_encode_kernel(const void* __restrict
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // -- pass 2: rows from the last to the first ------------------------------------------------------------
+    // -- rows from the last to the first ---------------------------------------------------------------------
     uint32_t nwords = 0, x = RANS_L;
     uint16_t* out = reinterpret_cast<uint16_t*>(slot + g.slot_hdr);
     if (coded) {
-        if (fast && rows) rc.seek(rows - 1);
+        const bool fast = (b.ex & 63) == 0;
+        RowCursor rc;
+        rc.rpx = (uint32_t)b.ex >> 6;
+        rc.ey = (uint32_t)b.ey;
+        rc.xr = rc.y = rc.z = 0;
+        if (TS == 4 && fast && rows) rc.seek(rows - 1);
+        const size_t cbase = (size_t)c * g.chunk_elems;
         for (uint32_t rb = ((rows + RB - 1) / RB) * RB; rb > 0; rb -= RB) {
-            Model m[RB];
+            uint32_t code[RB], ev[RB];
             bool act[RB];
             uint2 e[RB];
 #pragma unroll
             for (int k = 0; k < RB; k++) {
                 const uint32_t r = rb - 1 - k, i = r * 64u + lane;
                 act[k] = r < rows && i < n;
-                const RowPos p = row_pos(r);
-                m[k] = model_of<TS>(vol, b.base, t, i, p, act[k]);
-                if (fast && r < rows) rc.prev();
+                code[k] = 0;
+                ev[k] = 0;
+                if (TS == 2) {
+                    if (act[k]) code[k] = static_cast<const uint32_t*>(codes)[cbase + i];
+                    ev[k] = code[k] >> 10;
+                } else {
+                    int32_t v = 0;
+                    if (act[k]) {
+                        code[k] = static_cast<const uint16_t*>(codes)[cbase + i];
+                        const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
+                        v = static_cast<const int32_t*>(vol)[b.base + off];
+                    }
+                    if (fast && r < rows) rc.prev();
+                    const uint32_t u = ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+                    uint32_t s_, nb_;
+                    symbol_of(u, s_, nb_, ev[k]);
+                }
             }
 #pragma unroll
-            for (int k = 0; k < RB; k++) e[k] = etab[m[k].ctx * NSYM + m[k].s];
+            for (int k = 0; k < RB; k++) e[k] = etab[code[k] & 0x3FFu];
 #pragma unroll
             for (int k = 0; k < RB; k++) {
+                const uint32_t s = (code[k] >> 4) & 63u;
+                const uint32_t nb = s < 32u ? 0u : s - 30u;
                 // raw bits, last step first (the decoder reads them low bits first)
 #pragma unroll
                 for (int j = (TS == 2 ? 1 : 2); j >= 0; j--) {
-                    const bool has = act[k] && m[k].nb > 12u * (uint32_t)j;
+                    const bool has = act[k] && nb > 12u * (uint32_t)j;
                     if (__ballot(has) == 0ull) continue;
-                    const uint32_t kk = min(m[k].nb - 12u * (uint32_t)j, 12u);      // garbage where !has
+                    const uint32_t kk = min(nb - 12u * (uint32_t)j, 12u);      // garbage where !has
                     const uint32_t f = RANS_M >> (has ? kk : 0u);
                     renorm_put(x, f, has, out, nwords);
                     if (has) {
-                        const uint32_t val = (m[k].e >> (12 * j)) & ((1u << kk) - 1u);
+                        const uint32_t val = (ev[k] >> (12 * j)) & ((1u << kk) - 1u);
                         x = ((x >> (12u - kk)) << RANS_BITS) | (x & (f - 1u)) | (val << (12u - kk));
                     }
                 }
@@ -323,8 +459,8 @@ __global__ __launch_bounds__(64) void rans2_encode_kernel(const void* __restrict
         slot[3] = (uint8_t)TS;
         uint32_t* h = reinterpret_cast<uint32_t*>(slot);
         h[1] = n;
-        h[2] = t.ey;
-        h[3] = t.ex;
+        h[2] = (uint32_t)b.ey;
+        h[3] = (uint32_t)b.ex;
         h[4] = nwords;
         *reinterpret_cast<uint32_t*>(slot + SLOT2_TABLEN) = toff;
         sizes[c] = (uint32_t)HDR2 + toff + 2u * nwords;
@@ -562,21 +698,51 @@ void codec2_slot_layout(size_t chunk_elems, int ts, size_t& slot_hdr, size_t& sl
     slot_bytes = slot_hdr + ((2 * ((size_t)(ts == 2 ? 3 : 4) * chunk_elems + 128) + 15) & ~(size_t)15);
 }
 
+size_t codec2_work_bytes(const CodecGeom& g) {
+    // packed codes of every element (u32 / u16) + the 16 x 64 histogram of every chunk
+    return (((size_t)g.nchunks * g.chunk_elems * (g.ts == 2 ? 4 : 2) + 255) & ~(size_t)255) +
+           (size_t)g.nchunks * NCTX * NSYM * sizeof(uint32_t);
+}
+
 hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32_t* rcp_tab, uint8_t* slots,
-                               uint32_t* sizes, uint8_t* out, const unsigned long long* offsets, int stage,
-                               hipStream_t s) {
+                               uint8_t* work, uint32_t* sizes, uint8_t* out, const unsigned long long* offsets,
+                               int stage, hipStream_t s) {
     const uint2* rt = reinterpret_cast<const uint2*>(rcp_tab);
-    if (stage == 0) {
-        if (g.ts == 2)
-            hipLaunchKernelGGL(rans2_encode_kernel<2>, dim3((unsigned)g.nchunks), dim3(64), 0, s, vol, g, rt, slots,
-                               sizes);
-        else
-            hipLaunchKernelGGL(rans2_encode_kernel<4>, dim3((unsigned)g.nchunks), dim3(64), 0, s, vol, g, rt, slots,
-                               sizes);
-    } else {
+    if (stage == 1) {
         hipLaunchKernelGGL(rans2_pack_kernel, dim3((unsigned)g.nchunks), dim3(256), 0, s, slots, g, offsets, sizes,
                            out);
+        return hipGetLastError();
     }
+    void* codes = work;
+    const size_t cbytes = ((size_t)g.nchunks * g.chunk_elems * (g.ts == 2 ? 4 : 2) + 255) & ~(size_t)255;
+    uint32_t* ghist = reinterpret_cast<uint32_t*>(work + cbytes);
+    hipError_t e = hipMemsetAsync(ghist, 0, (size_t)g.nchunks * NCTX * NSYM * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const size_t plane = (size_t)g.cy * g.cx;
+    // every chunk of the volume has ex = min(cx, rest): the planes form applies when all of them do
+    const bool planes = g.ts == 2 && (g.cx % 64) == 0 && (g.nx % g.cx) == 0 && plane <= 4096;
+    if (planes) {
+        const int rp = (int)(plane / 64);                                  // rows per plane, <= 64
+        const int ppb = MODEL_ROWS / rp > 0 ? MODEL_ROWS / rp : 1;         // planes per workgroup
+        const int bpc = (g.cz + ppb - 1) / ppb;
+        hipLaunchKernelGGL(rans2_model_planes_kernel, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
+                           static_cast<const uint16_t*>(vol), g, bpc, ppb, static_cast<uint32_t*>(codes), ghist);
+    } else {
+        const size_t rows = (g.chunk_elems + 63) / 64;
+        const int bpc = (int)((rows + MODEL_ROWS - 1) / MODEL_ROWS);
+        if (g.ts == 2)
+            hipLaunchKernelGGL(rans2_model_kernel<2>, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
+                               vol, g, bpc, codes, ghist);
+        else
+            hipLaunchKernelGGL(rans2_model_kernel<4>, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
+                               vol, g, bpc, codes, ghist);
+    }
+    if (g.ts == 2)
+        hipLaunchKernelGGL(rans2_code_kernel<2>, dim3((unsigned)g.nchunks), dim3(64), 0, s, vol, g, rt, codes, ghist,
+                           slots, sizes);
+    else
+        hipLaunchKernelGGL(rans2_code_kernel<4>, dim3((unsigned)g.nchunks), dim3(64), 0, s, vol, g, rt, codes, ghist,
+                           slots, sizes);
     return hipGetLastError();
 }
 

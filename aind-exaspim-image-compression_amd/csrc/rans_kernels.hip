@@ -572,6 +572,7 @@ int make_codec_geom(int ts, int nz, int ny, int nx, int cz, int cy, int cx, Code
     g.slot_plane = ((size_t)2 * ((size_t)cn + 128) + 15) & ~(size_t)15;
     g.slot_bytes = g.slot_hdr + (size_t)ts * g.slot_plane;
     g.version = version;
+    g.chunk_elems = (size_t)cn;
     if (version == 2) {
         g.slot_plane = 0;
         codec2_slot_layout((size_t)cn, ts, g.slot_hdr, g.slot_bytes);
@@ -614,7 +615,8 @@ hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_
                               uint8_t* out, hipStream_t s) {
     const uint2* rt = reinterpret_cast<const uint2*>(rcp_tab);
     if (g.version == 2) {
-        const hipError_t e = launch_rans2_encode(vol, g, rcp_tab, slots, sizes, nullptr, nullptr, 0, s);
+        uint8_t* work = slots + (((size_t)g.nchunks * g.slot_bytes + 255) & ~(size_t)255);
+        const hipError_t e = launch_rans2_encode(vol, g, rcp_tab, slots, work, sizes, nullptr, nullptr, 0, s);
         if (e != hipSuccess) return e;
     } else if (g.ts == 2)
         hipLaunchKernelGGL((rans_encode_kernel<2, EXABM4D_ENC_PP>), dim3((unsigned)g.nchunks), dim3(128 / EXABM4D_ENC_PP), 0, s, vol, g, rt,
@@ -624,7 +626,7 @@ hipError_t launch_rans_encode(const void* vol, const CodecGeom& g, const uint32_
                            slots, sizes);
     hipLaunchKernelGGL(rans_scan_kernel, dim3(1), dim3(1024), 0, s, sizes, g.nchunks, offsets, totals);
     if (out) {
-        if (g.version == 2) return launch_rans2_encode(vol, g, rcp_tab, slots, sizes, out, offsets, 1, s);
+        if (g.version == 2) return launch_rans2_encode(vol, g, rcp_tab, slots, nullptr, sizes, out, offsets, 1, s);
         if (g.ts == 2)
             hipLaunchKernelGGL(rans_pack_kernel<2>, dim3((unsigned)g.nchunks), dim3(256), 0, s, slots, g,
                                offsets, sizes, out);

@@ -1,0 +1,63 @@
+"""Encode legs alone on a resident denoised 1024^3 volume (tools: iterate on the coder without the
+BM4D step): lossless EXAC of the uint16 volume and EXAC of the int32 DCT indices, ms per call from HIP
+events, for both format versions.
+
+    python tools/bench_exac.py [edge=1024] [reps=5]
+    rocprofv3 --kernel-trace --stats -d gpurun_out/x -- python tools/bench_exac.py      # per kernel"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "aind-exaspim-image-compression_amd"))
+sys.path.insert(0, ROOT)
+
+from aind_exaspim_image_compression import _native  # noqa: E402
+from bench import CHUNK, OFFSET, Q_STEP, SIGMA, synth_u16  # noqa: E402
+
+
+def main():
+    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    shape = (edge,) * 3
+    n = edge ** 3
+    ctx = _native.context(0)
+    d_in = ctx.to_device(synth_u16(shape, 1000))
+    d_den = ctx.alloc(2 * n)
+    ctx.denoise_u16(d_in, d_den, shape, SIGMA, OFFSET)
+    ctx.sync()
+    nblk = (-(-edge // 8)) ** 3
+    d_idx = ctx.alloc(4 * nblk * 512)
+    ctx.dctq_forward(d_den, shape, Q_STEP, d_idx)
+    legs = {"u16": (d_den, 2, shape, CHUNK), "raw_u16": (d_in, 2, shape, CHUNK),
+            "idx": (d_idx, 4, (nblk, 8, 64), (512, 8, 64))}
+    out = {"edge": edge}
+    ev = [ctx.event(), ctx.event()]
+    for version in (2, 1):
+        ctx.set_option("codec_version", version)
+        for name, (buf, ts, vshape, chunk) in legs.items():
+            nchunks = int(np.prod([-(-a // c) for a, c in zip(vshape, chunk)]))
+            cap = _native.codec_volume_bound(ts, vshape, chunk)
+            d_out, d_off, d_sz = ctx.alloc(cap), ctx.alloc(8 * (nchunks + 1)), ctx.alloc(4 * nchunks)
+            tot = ctx.codec_encode(buf, ts, vshape, chunk, out=d_out, out_capacity=cap, offsets=d_off, sizes=d_sz)
+            ctx.record(ev[0])
+            for _ in range(reps):
+                ctx.codec_encode(buf, ts, vshape, chunk, out=d_out, out_capacity=cap, offsets=d_off, sizes=d_sz,
+                                 totals=False)
+            ctx.record(ev[1])
+            ctx.sync()
+            ms = ctx.elapsed_ms(ev[0], ev[1]) / reps
+            nel = int(np.prod(vshape))
+            out[f"v{version}_{name}"] = {"ms": round(ms, 3), "coded_bytes": tot[0],
+                                         "bits_per_element": round(8.0 * tot[0] / nel, 4),
+                                         "GBps_in": round(ts * nel / ms / 1e6, 1)}
+            for b in (d_out, d_off, d_sz):
+                b.free()
+    ctx.set_option("codec_version", 2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
