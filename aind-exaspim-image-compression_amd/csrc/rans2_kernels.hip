@@ -235,73 +235,173 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_kernel(const voi
     }
 }
 
-// uint16 chunks whose rows are x-rows of the volume (ex a multiple of 64) and whose planes hold at
-// most 4096 elements -- the reference's 64^3 chunks: a workgroup walks MODEL_ROWS / (rows per plane)
-// planes, computes every residual ONCE (a wave keeps its rows' residuals in registers), publishes the
-// magnitudes of a plane in LDS, and reads the contexts' two magnitudes from there.
-__global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_planes_kernel(const uint16_t* __restrict__ vol,
+// uint16 chunks of 64-element rows and at most 64 rows per plane -- the reference's 64^3 chunks
+// (utils/img_util.py:401): no workgroup barrier and one residual per element.  A wave owns a strip of
+// 16 consecutive rows of every plane of its z-block and the lane is x: the tap above a row is the row
+// the wave has just loaded, the tap behind it is what the wave held for the plane before, and the
+// same holds for the two magnitudes of the context -- all in registers.  Only the strip's halo row
+// (the row above its first) is loaded and modelled a second time.
+constexpr int STRIP = 16;
+__global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_strips_kernel(const uint16_t* __restrict__ vol,
                                                                                CodecGeom g, int blocks_per_chunk,
                                                                                int planes_per_block,
                                                                                uint32_t* __restrict__ codes,
                                                                                uint32_t* __restrict__ ghist) {
-    constexpr int NC = EXABM4D_ENC2_NC, RPW = 16;            // rows of a plane per wave: <= 64 / MODEL_WAVES
+    constexpr int NC = EXABM4D_ENC2_NC;
     __shared__ uint32_t hist[NCTX * NSYM * NC];
-    __shared__ uint8_t mags[2][4096];
+    __shared__ uint8_t lut[256];
     const int c = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const ChunkBox b = chunk_box(g, c);
-    const uint32_t ex = (uint32_t)b.ex, ey = (uint32_t)b.ey, rpx = ex >> 6, rp = ey * rpx;   // rows per plane
-    const uint32_t ez = b.n / (ex * ey);
+    const uint32_t ey = (uint32_t)b.ey, ez = b.n / (64u * ey);
     const uint32_t z_lo = (uint32_t)blk * (uint32_t)planes_per_block, z_hi = min(ez, z_lo + (uint32_t)planes_per_block);
     for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM * NC); j += 64 * MODEL_WAVES) hist[j] = 0u;
-    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * g.ny;
-    const uint16_t* v16 = vol + b.base;
-    const size_t cbase = (size_t)c * g.chunk_elems;
-
-    // zigzag residual of row q (y = q / rpx, segment q % rpx) of plane z, this lane's element
-    auto resid = [&](uint32_t z, uint32_t q) -> uint32_t {
-        const uint32_t y = q / rpx, xr = q - y * rpx;
-        const size_t off = (size_t)z * sz + (size_t)y * sy + xr * 64u + lane;
-        const uint32_t v = v16[off];
-        const bool U = y > 0u, B = z > 0u;
-        const uint32_t vu = v16[U ? off - sy : off], vb = v16[B ? off - sz : off];
-        const uint32_t pred = U && B ? (vu + vb + 1u) >> 1 : (U ? vu : (B ? vb : 0u));
-        const int32_t r = (int32_t)(int16_t)(uint16_t)(v - pred);
-        return (uint32_t)(((r << 1) ^ (r >> 15)) & 0xFFFF);
-    };
-    if (z_lo < z_hi && z_lo > 0u) {           // magnitudes of the plane before the block
-        for (uint32_t q = wave; q < rp; q += MODEL_WAVES) mags[(z_lo - 1u) & 1u][q * 64u + lane] = (uint8_t)mag_of(resid(z_lo - 1u, q));
+    lut[threadIdx.x] = (uint8_t)ctx_of_activity(threadIdx.x);
+    __syncthreads();
+    const uint32_t q0 = wave * STRIP;                       // first row of the strip
+    if (z_lo < z_hi && q0 < ey) {
+        const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * g.ny;
+        const uint16_t* v16 = vol + b.base + lane;
+        uint32_t* crow = codes + (size_t)c * g.chunk_elems + lane;
+        auto zig = [](uint32_t v, uint32_t pred) -> uint32_t {
+            const int32_t r = (int32_t)(int16_t)(uint16_t)(v - pred);
+            return (uint32_t)(((r << 1) ^ (r >> 15)) & 0xFFFF);
+        };
+        // prediction of a voxel whose taps are given; U / B say which exist
+        auto pred_of = [](uint32_t vu, uint32_t vb, bool U, bool B) -> uint32_t {
+            return U && B ? (vu + vb + 1u) >> 1 : (U ? vu : (B ? vb : 0u));
+        };
+        uint32_t vprev[STRIP], mprev[STRIP];
+#pragma unroll
+        for (int k = 0; k < STRIP; k++) vprev[k] = mprev[k] = 0u;
+        if (z_lo > 0u) {                                     // plane before the block: values and magnitudes
+            const size_t zo = (size_t)(z_lo - 1u) * sz;
+            const bool B = z_lo > 1u;
+            uint32_t vb2[STRIP];
+            uint32_t vh = 0u;
+            if (q0 > 0u) vh = v16[zo + (size_t)(q0 - 1u) * sy];
+#pragma unroll
+            for (int k = 0; k < STRIP; k++) {
+                const uint32_t q = q0 + k;
+                vprev[k] = q < ey ? v16[zo + (size_t)q * sy] : 0u;
+                vb2[k] = (q < ey && B) ? v16[zo - sz + (size_t)q * sy] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < STRIP; k++) {
+                const uint32_t q = q0 + k;
+                const uint32_t up = k ? vprev[k ? k - 1 : 0] : vh;
+                mprev[k] = mag_of(zig(vprev[k], pred_of(up, vb2[k], q > 0u, B)));
+            }
+        }
+        for (uint32_t z = z_lo; z < z_hi; z++) {
+            const size_t zo = (size_t)z * sz;
+            const bool B = z > 0u;
+            uint32_t v[STRIP], m[STRIP];
+#pragma unroll
+            for (int k = 0; k < STRIP; k++) {
+                const uint32_t q = q0 + k;
+                v[k] = q < ey ? v16[zo + (size_t)q * sy] : 0u;
+            }
+            // halo row q0 - 1: its value (tap of the strip's first row) and its magnitude
+            uint32_t vh = 0u, mh = 0u;
+            if (q0 > 0u) {
+                const size_t ho = zo + (size_t)(q0 - 1u) * sy;
+                vh = v16[ho];
+                const uint32_t vhu = q0 > 1u ? v16[ho - sy] : 0u;
+                const uint32_t vhb = B ? v16[ho - sz] : 0u;
+                mh = mag_of(zig(vh, pred_of(vhu, vhb, q0 > 1u, B)));
+            }
+#pragma unroll
+            for (int k = 0; k < STRIP; k++) {
+                const uint32_t q = q0 + k;
+                if (q >= ey) break;                          // wave-uniform
+                const bool U = q > 0u;
+                const uint32_t up = k ? v[k ? k - 1 : 0] : vh;
+                const uint32_t u = zig(v[k], pred_of(up, vprev[k], U, B));
+                m[k] = mag_of(u);
+                const uint32_t mu = k ? m[k ? k - 1 : 0] : mh, mb = mprev[k];
+                const uint32_t a = U && B ? mu + mb : (U ? 2u * mu : (B ? 2u * mb : 0u));
+                const uint32_t ctx = lut[a];
+                uint32_t sy_, nb_, e_;
+                symbol_of(u, sy_, nb_, e_);
+                atomicAdd(&hist[(ctx * NSYM + sy_) * NC + (lane & (NC - 1))], 1u);
+                crow[((size_t)z * ey + q) * 64u] = ctx | (sy_ << 4) | (e_ << 10);
+            }
+#pragma unroll
+            for (int k = 0; k < STRIP; k++) {
+                vprev[k] = v[k];
+                mprev[k] = (q0 + k < ey) ? m[k] : 0u;
+            }
+        }
     }
     __syncthreads();
-    for (uint32_t z = z_lo; z < z_hi; z++) {
-        uint32_t u[RPW];
+    uint32_t* gh = ghist + (size_t)c * (NCTX * NSYM);
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM); j += 64 * MODEL_WAVES) {
+        uint32_t v = 0;
 #pragma unroll
-        for (int k = 0; k < RPW; k++) {
-            const uint32_t q = wave + (uint32_t)k * MODEL_WAVES;
-            u[k] = q < rp ? resid(z, q) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < RPW; k++) {
-            const uint32_t q = wave + (uint32_t)k * MODEL_WAVES;
-            if (q < rp) mags[z & 1u][q * 64u + lane] = (uint8_t)mag_of(u[k]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < RPW; k++) {
-            const uint32_t q = wave + (uint32_t)k * MODEL_WAVES;
-            if (q >= rp) continue;
-            const bool U = q >= rpx, B = z > 0u;
-            const uint32_t mu = U ? mags[z & 1u][(q - rpx) * 64u + lane] : 0u;
-            const uint32_t mb = B ? mags[(z - 1u) & 1u][q * 64u + lane] : 0u;
-            const uint32_t a = U && B ? mu + mb : (U ? 2u * mu : (B ? 2u * mb : 0u));
-            Model m;
-            symbol_of(u[k], m.s, m.nb, m.e);
-            m.ctx = ctx_of_activity(a);
-            atomicAdd(&hist[(m.ctx * NSYM + m.s) * NC + (lane & (NC - 1))], 1u);
-            codes[cbase + ((size_t)z * rp + q) * 64u + lane] = m.ctx | (m.s << 4) | (m.e << 10);
-        }
-        __syncthreads();
+        for (int k = 0; k < NC; k++) v += hist[j * NC + k];
+        if (v) atomicAdd(&gh[j], v);
     }
+}
+
+// int32 chunks whose rows are x-rows of the volume (ex a multiple of 64): the residual of an element is
+// the zigzag of its value, so a row needs three coalesced loads -- itself, the row above, the row a
+// plane before, all from wave-uniform bases -- and no per-lane index arithmetic.  This is the form of
+// the DCT-index leg (chunks of 512 blocks x 8 x 64 coefficients).
+__global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_rows32_kernel(const int32_t* __restrict__ vol,
+                                                                               CodecGeom g, int blocks_per_chunk,
+                                                                               uint16_t* __restrict__ codes,
+                                                                               uint32_t* __restrict__ ghist) {
+    constexpr int NC = EXABM4D_ENC2_NC, RB = 8;
+    __shared__ uint32_t hist[NCTX * NSYM * NC];
+    __shared__ uint8_t lut[256];
+    const int c = blockIdx.x / blocks_per_chunk, blk = blockIdx.x % blocks_per_chunk;
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const ChunkBox b = chunk_box(g, c);
+    const uint32_t rows = b.n >> 6;                          // whole rows only (ex is a multiple of 64)
+    const uint32_t r_lo = (uint32_t)blk * MODEL_ROWS, r_hi = min(rows, r_lo + (uint32_t)MODEL_ROWS);
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM * NC); j += 64 * MODEL_WAVES) hist[j] = 0u;
+    lut[threadIdx.x] = (uint8_t)ctx_of_activity(threadIdx.x);
+    __syncthreads();
+    if (r_lo < r_hi) {
+        const uint32_t ex = (uint32_t)b.ex, ey = (uint32_t)b.ey, rpx = ex >> 6;
+        const bool use_u = ex <= TAP_LIMIT, use_b = (uint64_t)ex * ey <= TAP_LIMIT;
+        const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * g.ny;
+        const int32_t* v32 = vol + b.base + lane;
+        uint16_t* crow = codes + (size_t)c * g.chunk_elems + lane;
+        auto zz = [](int32_t v) -> uint32_t { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); };
+        RowCursor rc;
+        rc.rpx = rpx;
+        rc.ey = ey;
+        for (uint32_t r0 = r_lo + wave * RB; r0 < r_hi; r0 += MODEL_WAVES * RB) {
+            rc.seek(r0);
+            int32_t v[RB], vu[RB], vb[RB];
+            bool U[RB], B[RB];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const bool act = r0 + k < r_hi;              // wave-uniform
+                const size_t off = act ? ((size_t)rc.z * sz + (size_t)rc.y * sy + rc.xr * 64u) : 0;
+                U[k] = act && use_u && rc.y > 0u;
+                B[k] = act && use_b && rc.z > 0u;
+                v[k] = v32[off];
+                vu[k] = v32[U[k] ? off - sy : off];
+                vb[k] = v32[B[k] ? off - sz : off];
+                if (r0 + k + 1 < r_hi) rc.next();
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                if (r0 + k >= r_hi) break;
+                const uint32_t mu = mag_of(zz(vu[k])), mb = mag_of(zz(vb[k]));
+                const uint32_t a = U[k] && B[k] ? mu + mb : (U[k] ? 2u * mu : (B[k] ? 2u * mb : 0u));
+                const uint32_t ctx = lut[a];
+                uint32_t s_, nb_, e_;
+                symbol_of(zz(v[k]), s_, nb_, e_);
+                atomicAdd(&hist[(ctx * NSYM + s_) * NC + (lane & (NC - 1))], 1u);
+                crow[(size_t)(r0 + k) * 64u] = (uint16_t)(ctx | (s_ << 4));
+            }
+        }
+    }
+    __syncthreads();
     uint32_t* gh = ghist + (size_t)c * (NCTX * NSYM);
     for (uint32_t j = threadIdx.x; j < (uint32_t)(NCTX * NSYM); j += 64 * MODEL_WAVES) {
         uint32_t v = 0;
@@ -385,6 +485,9 @@ __global__ __launch_bounds__(64) void rans2_code_kernel(const void* __restrict__
     __builtin_amdgcn_wave_barrier();
 
     // -- rows from the last to the first ---------------------------------------------------------------------
+    // The last rows -- a partial row, and whatever keeps the rest from being whole batches -- go one
+    // at a time with a per-lane predicate; all other rows are whole and run as batches of RB with
+    // nothing predicated: RB code loads and table look-ups in flight, then the serial state chain.
     uint32_t nwords = 0, x = RANS_L;
     uint16_t* out = reinterpret_cast<uint16_t*>(slot + g.slot_hdr);
     if (coded) {
@@ -393,60 +496,84 @@ __global__ __launch_bounds__(64) void rans2_code_kernel(const void* __restrict__
         rc.rpx = (uint32_t)b.ex >> 6;
         rc.ey = (uint32_t)b.ey;
         rc.xr = rc.y = rc.z = 0;
-        if (TS == 4 && fast && rows) rc.seek(rows - 1);
         const size_t cbase = (size_t)c * g.chunk_elems;
-        for (uint32_t rb = ((rows + RB - 1) / RB) * RB; rb > 0; rb -= RB) {
-            uint32_t code[RB], ev[RB];
-            bool act[RB];
-            uint2 e[RB];
-#pragma unroll
-            for (int k = 0; k < RB; k++) {
-                const uint32_t r = rb - 1 - k, i = r * 64u + lane;
-                act[k] = r < rows && i < n;
-                code[k] = 0;
-                ev[k] = 0;
-                if (TS == 2) {
-                    if (act[k]) code[k] = static_cast<const uint32_t*>(codes)[cbase + i];
-                    ev[k] = code[k] >> 10;
-                } else {
-                    int32_t v = 0;
-                    if (act[k]) {
-                        code[k] = static_cast<const uint16_t*>(codes)[cbase + i];
-                        const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
-                        v = static_cast<const int32_t*>(vol)[b.base + off];
-                    }
-                    if (fast && r < rows) rc.prev();
-                    const uint32_t u = ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
-                    uint32_t s_, nb_;
-                    symbol_of(u, s_, nb_, ev[k]);
+        const uint32_t* c32 = static_cast<const uint32_t*>(codes) + (TS == 2 ? cbase : 0);
+        const uint16_t* c16 = static_cast<const uint16_t*>(codes) + (TS == 4 ? cbase : 0);
+
+        // code word and raw value of element i of row r
+        auto fetch = [&](uint32_t r, uint32_t i, bool act, uint32_t& code, uint32_t& ev) {
+            if (TS == 2) {
+                code = act ? c32[i] : 0u;
+                ev = code >> 10;
+            } else {
+                int32_t v = 0;
+                code = 0u;
+                if (act) {
+                    code = c16[i];
+                    const size_t off = fast ? rc.offset(g) + lane : elem_offset(g, b, i);
+                    v = static_cast<const int32_t*>(vol)[b.base + off];
                 }
+                const uint32_t u = ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+                uint32_t s_, nb_;
+                symbol_of(u, s_, nb_, ev);
             }
-#pragma unroll
-            for (int k = 0; k < RB; k++) e[k] = etab[code[k] & 0x3FFu];
-#pragma unroll
-            for (int k = 0; k < RB; k++) {
-                const uint32_t s = (code[k] >> 4) & 63u;
+        };
+        // one row through the coder: raw bits (last step first: the decoder reads them low bits
+        // first), then the symbol
+        auto code_row = [&](uint32_t code, uint32_t ev, uint2 e, bool act) {
+            if (__ballot(act && (code & 0x200u)) != 0ull) {          // a symbol >= 32 somewhere in the row
+                const uint32_t s = (code >> 4) & 63u;
                 const uint32_t nb = s < 32u ? 0u : s - 30u;
-                // raw bits, last step first (the decoder reads them low bits first)
 #pragma unroll
                 for (int j = (TS == 2 ? 1 : 2); j >= 0; j--) {
-                    const bool has = act[k] && nb > 12u * (uint32_t)j;
+                    const bool has = act && nb > 12u * (uint32_t)j;
                     if (__ballot(has) == 0ull) continue;
                     const uint32_t kk = min(nb - 12u * (uint32_t)j, 12u);      // garbage where !has
                     const uint32_t f = RANS_M >> (has ? kk : 0u);
                     renorm_put(x, f, has, out, nwords);
                     if (has) {
-                        const uint32_t val = (ev[k] >> (12 * j)) & ((1u << kk) - 1u);
+                        const uint32_t val = (ev >> (12 * j)) & ((1u << kk) - 1u);
                         x = ((x >> (12u - kk)) << RANS_BITS) | (x & (f - 1u)) | (val << (12u - kk));
                     }
                 }
-                const uint32_t f = e[k].x & 0x1FFFu;
-                renorm_put(x, f, act[k], out, nwords);
-                if (act[k]) {
-                    const uint32_t qd = __umulhi(x, e[k].y) >> (e[k].x >> 26);
-                    x = x + ((e[k].x >> 13) & 0x1FFFu) + qd * (RANS_M - f);
-                }
             }
+            const uint32_t f = e.x & 0x1FFFu;
+            const bool emit = act && x >= (e.x << 19);               // F << 19: the upper fields shift out
+            const uint64_t em = __ballot(emit);
+            if (emit) {
+                out[nwords + rank_below(em)] = (uint16_t)(x & 0xFFFFu);
+                x >>= 16;
+            }
+            nwords += (uint32_t)__popcll(em);
+            const uint32_t qd = __umulhi(x, e.y) >> (e.x >> 26);
+            const uint32_t nx = x + ((e.x >> 13) & 0x1FFFu) + qd * (RANS_M - f);
+            x = act ? nx : x;
+        };
+
+        const uint32_t whole = n >> 6;                               // rows without an inactive lane
+        const uint32_t batched = (whole / RB) * RB;                  // rows [0, batched) run as batches
+        if (TS == 4 && fast && rows) rc.seek(rows - 1);
+        for (uint32_t r = rows; r > batched; r--) {
+            const uint32_t i = (r - 1u) * 64u + lane;
+            const bool act = i < n;
+            uint32_t code, ev;
+            fetch(r - 1u, i, act, code, ev);
+            if (TS == 4 && fast) rc.prev();
+            code_row(code, ev, etab[code & 0x3FFu], act);
+        }
+        for (uint32_t rb = batched; rb > 0; rb -= RB) {
+            uint32_t code[RB], ev[RB];
+            uint2 e[RB];
+#pragma unroll
+            for (int k = 0; k < RB; k++) {
+                const uint32_t r = rb - 1 - k;
+                fetch(r, r * 64u + lane, true, code[k], ev[k]);
+                if (TS == 4 && fast) rc.prev();
+            }
+#pragma unroll
+            for (int k = 0; k < RB; k++) e[k] = etab[code[k] & 0x3FFu];
+#pragma unroll
+            for (int k = 0; k < RB; k++) code_row(code[k], ev[k], e[k], true);
         }
         out[nwords + 2 * lane] = (uint16_t)(x & 0xFFFFu);
         out[nwords + 2 * lane + 1] = (uint16_t)(x >> 16);
@@ -718,15 +845,18 @@ hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32
     uint32_t* ghist = reinterpret_cast<uint32_t*>(work + cbytes);
     hipError_t e = hipMemsetAsync(ghist, 0, (size_t)g.nchunks * NCTX * NSYM * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
-    const size_t plane = (size_t)g.cy * g.cx;
-    // every chunk of the volume has ex = min(cx, rest): the planes form applies when all of them do
-    const bool planes = g.ts == 2 && (g.cx % 64) == 0 && (g.nx % g.cx) == 0 && plane <= 4096;
-    if (planes) {
-        const int rp = (int)(plane / 64);                                  // rows per plane, <= 64
-        const int ppb = MODEL_ROWS / rp > 0 ? MODEL_ROWS / rp : 1;         // planes per workgroup
+    // every chunk of the volume has ex = min(cx, rest of the row): the strips form needs 64 everywhere
+    const bool strips = g.ts == 2 && g.cx == 64 && (g.nx % 64) == 0 && g.cy <= STRIP * MODEL_WAVES;
+    if (strips) {
+        const int ppb = 16;                                                // planes per workgroup
         const int bpc = (g.cz + ppb - 1) / ppb;
-        hipLaunchKernelGGL(rans2_model_planes_kernel, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
+        hipLaunchKernelGGL(rans2_model_strips_kernel, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
                            static_cast<const uint16_t*>(vol), g, bpc, ppb, static_cast<uint32_t*>(codes), ghist);
+    } else if (g.ts == 4 && (g.cx % 64) == 0 && (g.nx % g.cx) == 0) {
+        const size_t rows = g.chunk_elems / 64;
+        const int bpc = (int)((rows + MODEL_ROWS - 1) / MODEL_ROWS);
+        hipLaunchKernelGGL(rans2_model_rows32_kernel, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
+                           static_cast<const int32_t*>(vol), g, bpc, static_cast<uint16_t*>(codes), ghist);
     } else {
         const size_t rows = (g.chunk_elems + 63) / 64;
         const int bpc = (int)((rows + MODEL_ROWS - 1) / MODEL_ROWS);

