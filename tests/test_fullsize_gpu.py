@@ -214,3 +214,57 @@ def test_config5_chain_at_1024(full1024, ctx):
     assert int(err.abs().max()) <= 0.5 * q * np.sqrt(512.0) + 1.0
     assert float(err.float().abs().mean()) < 0.5 * q
     assert exact_i < exact                                    # the lossy leg is the smaller one
+
+
+def test_config3_bm4dnet_stage_at_1024(full1024):
+    """BASELINE.json configs[2] is "two-stage BM4D + bm4dnet learned shrinkage" on a 1024^3 volume: the
+    learned stage -- inference.predict (reference inference.py:28-116; production call
+    scripts/evaluate_bm4dnet.py:136, :201) -- at the FULL size on the BM4D result: 8000 patches of
+    64^3, batch 32.  No oracle exists at this size, so the checks are properties: uint16 volume of
+    the input's shape; the reference's low-edge quirk (first `trim` voxels of every axis =
+    transform.inverse(0) = the offset, inference.py:91-103); and locality -- a 256^3 crop whose origin
+    lies on the patch grid (multiples of 52) predicted on its own gives the same voxels wherever
+    the same patches with the same content cover them (8 <= p < 212 per axis).  Run for the seeded
+    U-Net (fp32, random init: throughput and plumbing, not quality) and for an elementwise model,
+    whose result is also known in closed form."""
+    from aind_exaspim_image_compression import inference
+    from aind_exaspim_image_compression.machine_learning import transforms as T
+    from aind_exaspim_image_compression.machine_learning import unet3d
+    _, den = full1024
+    n = 1024
+    cfg = {"kind": "offset", "base": {"kind": "asinh", "params": {"offset": 0.0, "scale": 32.0}},
+           "params": {"offset": 37.0}}
+    tf = T.build_transform(cfg)
+    o = (520, 312, 208)
+    assert all(v % 52 == 0 for v in o)
+    crop = np.ascontiguousarray(den[o[0]:o[0] + 256, o[1]:o[1] + 256, o[2]:o[2] + 256])
+    inner = (slice(8, 212),) * 3
+    full_inner = tuple(slice(a + 8, a + 212) for a in o)
+
+    class Affine(torch.nn.Module):
+        def forward(self, x):
+            return x * 0.5 + 0.125
+
+    # (a) elementwise model: closed form + locality
+    out = inference.predict(den, Affine().cuda().eval(), tf, batch_size=32, verbose=False)
+    assert out.dtype == np.uint16 and out.shape == (n, n, n)
+    assert np.all(out[:5] == 37) and np.all(out[:, :5] == 37) and np.all(out[:, :, :5] == 37)
+    sub = inference.predict(crop, Affine().cuda().eval(), tf, batch_size=32, verbose=False)
+    np.testing.assert_array_equal(sub[inner], out[full_inner])
+    want = tf.inverse(tf.forward(crop[inner]) * np.float32(0.5) + np.float32(0.125))
+    d = np.abs(out[full_inner].astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-3          # mean of k equal fp32 values, k = 1 .. 8 patches
+    del out
+    # (b) the U-Net
+    torch.manual_seed(0)
+    model = unet3d.UNet().cuda().eval()
+    inference.predict(den[:64, :220, :428], model, tf, batch_size=32, verbose=False)    # one full batch: MIOpen warm-up
+    out = inference.predict(den, model, tf, batch_size=32, verbose=False)
+    assert out.dtype == np.uint16 and out.shape == (n, n, n)
+    assert np.all(out[:5] == 37) and np.all(out[:, :5] == 37) and np.all(out[:, :, :5] == 37)
+    assert inference.count_patches(inference._ShapeOnly((1, 1, n, n, n)), 64, 12) == 8000
+    sub = inference.predict(crop, model, tf, batch_size=32, verbose=False)
+    d = np.abs(sub[inner].astype(np.int32) - out[full_inner].astype(np.int32))
+    # same patches, same fp32 network; a patch may sit at another position of its batch
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (int(d.max()), float(np.mean(d > 0)))
+    assert out[full_inner].std() > 0                        # a real volume came back, not a constant
