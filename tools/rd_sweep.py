@@ -1,14 +1,18 @@
-"""Rate-distortion sweep of the denoise -> quantise -> (rate proxy) path on one MI355X
-(BASELINE.json config 5, with the pieces this repo has): for each BM4D sigma the synthetic uint16
-volume is denoised on the device, the rate is the order-0 entropy bound of the byte-shuffled
-64^3 chunks (`shuffled_entropy_cratio`, row f-1's proxy -- NOT Blosc-zstd bytes) and the
-distortion is SSIM / MAE against the noisy input (the reference's own report, evaluate.py:105:
-ssim3D(noise, denoised)), all reduced on the GPU (row f-4).
+"""Rate-distortion sweep of BASELINE.json config 5 -- BM4D denoise -> 8^3 block DCT quantise -> entropy
+encode -- on one MI355X with REAL coded bytes (EXAC v2 streams, the same calls bench.py times) and
+the codec family the reference ships (byte shuffle + zstd-5 per 64^3 chunk, libzstd via ctypes) next
+to the lossless points.  The volume, its denoised versions, indices and reconstructions stay in HBM;
+the host sees scalars (and, for zstd, a sample of chunks).
 
-A second sweep quantises the sigma = 24 result with the block-DCT quantiser of row f-1 at several
-steps: order-0 entropy of the indices in bits per voxel against MAE / max error / SSIM.
+The reference's own report is cratio(raw), cratio(denoised) and their ratio
+(scripts/evaluate_bm4dnet.py:138-145) plus ssim3D(noise, denoised) (evaluate.py:105).
 
-usage: python tools/rd_sweep.py [edge=512] [sigmas=0,8,16,24,32,48]"""
+    python tools/rd_sweep.py [edge=1024] [sigmas=0,8,16,24,32,48] [qs=1,2,4,8,16,32] > rd_sweep.json
+
+Axis 1 (lossless leg): for each BM4D sigma -- coded bytes of the denoised uint16 volume, distortion
+against the noisy input (MAE, SSIM) and against the clean volume (PSNR, on a 256^3 corner).
+Axis 2 (lossy leg): for each sigma and each step q -- coded bytes of the int32 indices, error of the
+reconstruction against the denoised volume (MAE, max) and PSNR against the clean corner."""
 import json
 import os
 import sys
@@ -20,39 +24,83 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "aind-exaspim-image-compression_amd"))
 sys.path.insert(0, ROOT)
 
-from aind_exaspim_image_compression.bm4d import denoise_volume  # noqa: E402
-from aind_exaspim_image_compression.utils import dct_quant, img_util  # noqa: E402
+from aind_exaspim_image_compression import _native  # noqa: E402
+from aind_exaspim_image_compression.utils import dct_quant  # noqa: E402
 import bench  # noqa: E402
 
 
-def main():
-    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    sigmas = [float(s) for s in (sys.argv[2] if len(sys.argv) > 2 else "0,8,16,24,32,48").split(",")]
+def sweep(edge, sigmas, qs, seed=1000, zstd_chunks=128, log=None):
+    from oracle import zstd_ref           # checker-side comparison only (tool, not product)
     shape = (edge,) * 3
-    noisy = bench.synth_u16(shape, 1)
+    n = edge ** 3
+    ctx = _native.context(0)
+    noisy = bench.synth_u16(shape, seed)
+    corner = min(edge, 256)
+    clean = bench.synth_clean((corner,) * 3, seed)
+    peak = float(clean.max() - clean.min())
+    csl = (slice(0, corner),) * 3
+    d_noisy, d_den, d_rec = ctx.to_device(noisy), ctx.alloc(2 * n), ctx.alloc(2 * n)
+    nblk = (-(-edge // 8)) ** 3
+    d_idx = ctx.alloc(4 * nblk * 512)
+    nchunks = (-(-edge // 64)) ** 3
+    d_sz = ctx.alloc(4 * nchunks)
+    pick = list(range(0, nchunks, max(1, nchunks // zstd_chunks)))
+    g = -(-edge // 64)
+
+    def box(c):
+        z, y, x = c // (g * g), (c // g) % g, c % g
+        return (slice(64 * z, 64 * z + 64), slice(64 * y, 64 * y + 64), slice(64 * x, 64 * x + 64))
+
     rows = []
     for sigma in sigmas:
         t0 = time.perf_counter()
-        den = noisy if sigma == 0 else denoise_volume(noisy, sigma, offset=bench.OFFSET)
+        if sigma > 0:
+            ctx.denoise_u16(d_noisy, d_den, shape, sigma, bench.OFFSET)
+            src = d_den
+        else:
+            src = d_noisy
+        coded, _ = ctx.codec_encode(src, 2, shape, bench.CHUNK, sizes=d_sz)
+        ctx.sync()
         dt = time.perf_counter() - t0
-        rows.append({
-            "sigma": sigma,
-            "entropy_cratio": img_util.shuffled_entropy_cratio(den),
-            "mae_vs_noisy": img_util.compute_mae(den, noisy),
-            "ssim_vs_noisy": float(img_util.ssim3D(noisy, den, data_range=np.max(noisy))),
-            "seconds_host_to_host": round(dt, 3),
-        })
-        print(json.dumps(rows[-1]), flush=True)
-    # second axis of the sweep: the transform quantiser on the sigma = 24 result
-    den = denoise_volume(noisy, 24.0, offset=bench.OFFSET)
-    qrows = []
-    for q in (1.0, 2.0, 4.0, 8.0, 16.0, 32.0):
-        rd = dct_quant.rate_distortion(den, q)
-        rec = dct_quant.reconstruct(dct_quant.quantise(den, q), den.shape, q)
-        rd["ssim_vs_denoised"] = float(img_util.ssim3D(den, rec, data_range=np.max(den)))
-        qrows.append(rd)
-        print(json.dumps(rd), flush=True)
-    print(json.dumps({"volume": shape, "rows": rows, "dct_quantiser_on_sigma24": qrows}))
+        den = src.download(shape, np.uint16)
+        sizes = d_sz.download((nchunks,), np.uint32).astype(np.uint64)
+        err = ctx.masked_error_stats(src, np.uint16, d_noisy, np.uint16, None, n)
+        ssim = ctx.ssim3d_sum(d_noisy, src, np.uint16, shape, 16, (0.01 * float(noisy.max())) ** 2,
+                              (0.03 * float(noisy.max())) ** 2) / n
+        row = {"sigma": sigma, "lossless_bytes": int(coded), "cratio": 2.0 * n / coded,
+               "bits_per_voxel": 8.0 * coded / n, "mae_vs_noisy": float(err[1] / n),
+               "ssim_vs_noisy": float(ssim), "psnr_vs_clean_db": bench.psnr_db(den[csl], clean, peak),
+               "device_seconds_denoise_plus_encode": round(dt, 3)}
+        if zstd_ref.available():
+            zs = sum(zstd_ref.shuffle_zstd_size(den[box(c)], 5) for c in pick)
+            row["cratio_zstd5_shuffle_sampled"] = float(sum(den[box(c)].nbytes for c in pick)) / zs
+            row["cratio_same_chunks"] = float(sum(den[box(c)].nbytes for c in pick)) / float(sizes[pick].sum())
+        row["dct"] = []
+        for q in qs:
+            rd = dct_quant.rate_distortion_device(ctx, src, shape, q, d_idx=d_idx, d_rec=d_rec)
+            rec = d_rec.download(shape, np.uint16)
+            rd["psnr_vs_clean_db"] = bench.psnr_db(rec[csl], clean, peak)
+            rd["psnr_vs_denoised_db"] = bench.psnr_db(rec[csl], den[csl], peak)
+            row["dct"].append(rd)
+        rows.append(row)
+        if log:
+            print(json.dumps(row), file=log, flush=True)
+    for b in (d_noisy, d_den, d_rec, d_idx, d_sz):
+        b.free()
+    return {"volume": list(shape), "seed": seed, "offset": bench.OFFSET, "noise_sigma": bench.SIGMA,
+            "codec": "EXAC v2 (DESIGN.md 3.11b): 64^3 chunks of the uint16 volume; chunks of 512 blocks x 8 x 64 "
+                     "of the int32 indices",
+            "psnr_peak": peak, "psnr_region": f"{corner}^3 corner against the clean volume",
+            "zstd": (f"libzstd {zstd_ref.version()} level 5 on byte-shuffled 64^3 chunks, {len(pick)} sampled chunks"
+                     if zstd_ref.available() else None),
+            "rows": rows}
+
+
+def main():
+    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    sigmas = [float(s) for s in (sys.argv[2] if len(sys.argv) > 2 else "0,8,16,24,32,48").split(",")]
+    qs = [float(s) for s in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8,16,32").split(",")]
+    print(json.dumps(sweep(edge, sigmas, qs, log=sys.stderr), indent=1))
 
 
 if __name__ == "__main__":
