@@ -328,6 +328,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->bm_int = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "stage_quads") == 0) {        // Wiener stage: four (1) or two (0) waves per group
+        g_stage_quads = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "stage_chunks") == 0) {       // diagnostic: z chunks of the stage kernels
         g_stage_chunks = value > 0 ? value : 0;
         return EXABM4D_OK;

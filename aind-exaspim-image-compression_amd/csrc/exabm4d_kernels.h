@@ -59,6 +59,7 @@ hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
                              const uint16_t* vol16 = nullptr);
+extern int g_stage_quads;    // Wiener stage: 1 = four waves per group (stage_quad_kernel), 0 = two (stage_half_kernel<true>)
 extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chunk count (0 = automatic)
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,

@@ -1391,6 +1391,461 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
 #endif
 }
 
+// =================================================================================================
+// Wiener stage, FOUR waves per group ("quarter groups"; round 3).
+//
+// The two-waves-per-group Wiener kernel above holds two half spectra (noisy and basic estimate: 128
+// spectrum registers, 245 in all) and is held at two waves per SIMD; the hard-threshold kernel gained
+// 11 % from its third wave.  The Haar transform along the group splits one level further: a member m
+// of a team of four transforms blocks [m K/4, (m+1) K/4), runs the log2(K/4) local levels and the
+// Wiener filter of its detail coefficients, and the last TWO levels act on the four members'
+// approximation coefficients only.  Those (8 float2 per lane and member: four coefficient-plane
+// pairs of the noisy and of the basic spectrum) go through the transpose buffers, every member
+// evaluates the two top levels redundantly -- the same operations in the same order as the oracle's
+// recursion, so spectra stay bit-identical -- and keeps its own quarter.  Two spectra of at most 4
+// blocks are 64 registers: twelve waves (three teams) per workgroup, three per SIMD.
+// Groups of 8 / 4 blocks give every member 2 / 1; a group of 2 occupies two members, a group of 1
+// one; the others idle through it (and still report to the layer counter).
+// =================================================================================================
+#ifndef EXABM4D_WIE_QUADS
+#define EXABM4D_WIE_QUADS 1                    // 0: the Wiener stage runs the two-waves-per-group kernel
+#endif
+#ifndef EXABM4D_QUAD_NW
+#define EXABM4D_QUAD_NW 12
+#endif
+#ifndef EXABM4D_QUAD_TY
+#define EXABM4D_QUAD_TY 2
+#endif
+#ifndef EXABM4D_QUAD_TX
+#define EXABM4D_QUAD_TX 4
+#endif
+#ifndef EXABM4D_QUAD_NPL
+#define EXABM4D_QUAD_NPL 18
+#endif
+struct QuadCfg : HalfGeom<EXABM4D_QUAD_NW, EXABM4D_QUAD_TY, EXABM4D_QUAD_TX, EXABM4D_QUAD_NPL> {
+    static_assert(EXABM4D_QUAD_NW % 4 == 0, "teams of four waves");
+};
+typedef float f8v __attribute__((ext_vector_type(8)));
+
+// Local levels of a member with KQ blocks: Haar over its blocks of both spectra, Wiener-filter its
+// detail coefficients, hand back the approximation pairs (noisy [0, 4), basic [4, 8)).
+template <int KQ>
+__device__ __forceinline__ void wiener_quarter_local(f8v (&S)[4], const f8v (&SB)[4], float sigma2, float& sw,
+                                                     f2 (&approx)[8]) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) {
+        f8v A = S[jp];
+        const f8v B = SB[jp];
+        f2 x[MAXG], y[MAXG];
+#pragma unroll
+        for (int k = 0; k < KQ; k++) {
+            x[k] = mk2(A[2 * k], A[2 * k + 1]);
+            y[k] = mk2(B[2 * k], B[2 * k + 1]);
+        }
+        haar_fwd2<KQ>(x);
+        haar_fwd2<KQ>(y);
+        approx[jp] = x[0];
+        approx[4 + jp] = y[0];
+#pragma unroll
+        for (int k = 1; k < KQ; k++) {
+            const f2 e = y[k] * y[k];
+            const f2 t = e + sigma2;
+            const f2 W = e * mk2(__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y));
+            sw += W.x * W.x;
+            sw += W.y * W.y;
+            const f2 f = W * x[k];
+            A[2 * k] = f.x;
+            A[2 * k + 1] = f.y;
+        }
+        S[jp] = A;
+    }
+}
+template <int KQ>
+__device__ __forceinline__ void quarter_unshrink_local(f8v (&S)[4], const f2 (&approx)[4]) {
+#pragma unroll
+    for (int jp = 0; jp < 4; jp++) {
+        f8v A = S[jp];
+        f2 x[MAXG];
+        x[0] = approx[jp];
+#pragma unroll
+        for (int k = 1; k < KQ; k++) x[k] = mk2(A[2 * k], A[2 * k + 1]);
+        haar_inv2<KQ>(x);
+#pragma unroll
+        for (int k = 0; k < KQ; k++) {
+            A[2 * k] = x[k].x;
+            A[2 * k + 1] = x[k].y;
+        }
+        S[jp] = A;
+    }
+}
+// W = e / (e + sigma^2) of a packed pair, evaluated as e * rcp (see shrink_wiener); adds W^2 to sw
+__device__ __forceinline__ f2 wiener_w(f2 u, float sigma2, float& sw) {
+    const f2 e = u * u;
+    const f2 d = e + sigma2;
+    const f2 W = e * mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+    sw += W.x * W.x;
+    sw += W.y * W.y;
+    return W;
+}
+
+// One wave, one quarter of a group.  `sync` = int[2 * NW]: ready[w], ack[w]; `seq` = exchanges this
+// team has done so far (all four waves count alike, also the ones that idle through a small group).
+// Returns true for the wave that completes the layer.
+template <typename TableT>
+__device__ __forceinline__ bool process_quad_group(
+    const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
+    int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
+    const float* __restrict__ win_g, float sigma2, ring_t* ring, float* __restrict__ cvol, f2* tb,
+    f2* team_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int& seen, int layer, int target,
+    int lane, long long g_nvox) {
+    using C = QuadCfg;
+    constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, REG = C::COLS;
+    constexpr int NP = 8;                      // f2 values per lane a member publishes
+    const int hi = lane >> 3, lo = lane & 7;
+    const int member = wave & 3, team0 = wave & ~3;
+    const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
+    const int count = __popcll(__ballot(mykey != KEY_EMPTY));
+    int K = 1;
+    while (K * 2 <= count) K *= 2;
+    const int A = K < 4 ? K : 4;               // members that hold blocks
+    const int KQ = K > 4 ? K / 4 : 1;          // blocks per member
+    const int kb = member * KQ;                // first block of this member
+    const bool active = member < A;
+    if (K > 1) seq++;
+
+    auto body = [&](auto KQc) {
+        constexpr int KQ = decltype(KQc)::value;
+        f8v S[4], SB[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            S[j] = (f8v)(0.0f);
+            SB[j] = (f8v)(0.0f);
+        }
+        int my_dz, my_dy, my_dx;
+        code_to_disp(mykey & KEY_CMASK, my_dz, my_dy, my_dx);
+        const unsigned long long my_corner =
+            lane < MAXG ? (unsigned long long)(rz + my_dz) * sz +
+                              (unsigned long long)(ry + my_dy) * sy + (unsigned long long)(rx + my_dx)
+                        : 0ull;
+        const int zb = max(rz - RAD, 0);
+        const size_t win_off = (size_t)zb * sz;
+        const size_t win_left = (size_t)g_nvox - win_off;
+        const int win_bytes = (int)min(win_left * sizeof(float), (size_t)0x7FFFFFFFu * 2u);
+        const __amdgpu_buffer_rsrc_t noisy_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(noisy + win_off), 0, win_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t basic_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(basic + win_off), 0, win_bytes, 0x00020000);
+        const int my_rel = lane < MAXG ? (int)(4u * (unsigned)(my_corner - win_off)) : 0;
+        auto corner_of = [&](int k) -> int { return __builtin_amdgcn_readlane(my_rel, k); };
+        float a[8], b[8];
+        f2 v2[8];
+        unsigned voff[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+            voff[y] = 4u * ((unsigned)hi * (unsigned)sz + (unsigned)y * (unsigned)sy + (unsigned)lo);
+        if constexpr (KQ == 1) {
+            const size_t c0 = corner_of(kb);
+            gather8v(noisy_r, c0, voff, a);
+            gather8v(basic_r, c0, voff, b);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+            pair_fwd<false>(T, tb, hi, lo, v2);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                S[j >> 1][j & 1] = v2[j].x;
+                SB[j >> 1][j & 1] = v2[j].y;
+            }
+        } else {
+            gather8v(noisy_r, corner_of(kb), voff, a);
+            gather8v(noisy_r, corner_of(kb + 1), voff, b);
+#pragma unroll
+            for (int kl = 0; kl < KQ; kl += 2) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                gather8v(basic_r, corner_of(kb + kl), voff, a);
+                gather8v(basic_r, corner_of(kb + kl + 1), voff, b);
+                pair_fwd<false>(T, tb, hi, lo, v2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                    S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                if (kl + 2 < KQ) {
+                    gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
+                    gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
+                }
+                pair_fwd<false>(T, tb, hi, lo, v2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    SB[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                    SB[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
+                }
+            }
+        }
+
+        float sw = 0.0f;
+        f2 approx[NP];
+        wiener_quarter_local<KQ>(S, SB, sigma2, sw, approx);
+        f2 top[4];
+        if (K > 1) {
+            // publish: my transpose buffer is free (forward transforms done; every team mate
+            // acknowledged the previous exchange before my last inverse transforms started)
+#pragma unroll
+            for (int jp = 0; jp < NP; jp++) tb[jp * 64 + lane] = approx[jp];
+            tb[NP * 64 + lane] = mk2(sw, 0.0f);
+            raise_flag(sync + wave, seq, lane);
+            // wait for the team, then read its approximations plane pair by plane pair (member
+            // order; mine from registers) -- eight float2 live at a time instead of thirty-two
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (m < A && m != member) wait_flag(sync + team0 + m, seq, lane);
+            auto from = [&](int m, int idx) -> f2 {
+                return m == member ? approx[idx] : team_tb[(size_t)m * (C::TBW / 2) + idx * 64 + lane];
+            };
+            // weight statistic: the members' local sums in member order, then the top levels
+            {
+                const float own = sw;
+                auto stat = [&](int m) -> float {
+                    return m == member ? own : team_tb[(size_t)m * (C::TBW / 2) + NP * 64 + lane].x;
+                };
+                sw = stat(0);
+                sw += stat(1);
+                if (A > 2) {
+                    sw += stat(2);
+                    sw += stat(3);
+                }
+            }
+            if (A == 2) {
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) {
+                    const f2 a0 = from(0, jp), a1 = from(1, jp), b0 = from(0, 4 + jp), b1 = from(1, 4 + jp);
+                    f2 t0 = (a0 + a1) * HAAR_C, t1 = (a0 - a1) * HAAR_C;
+                    const f2 u0 = (b0 + b1) * HAAR_C, u1 = (b0 - b1) * HAAR_C;
+                    t0 = wiener_w(u0, sigma2, sw) * t0;
+                    t1 = wiener_w(u1, sigma2, sw) * t1;
+                    top[jp] = member ? (t0 - t1) * HAAR_C : (t0 + t1) * HAAR_C;
+                }
+            } else {
+#pragma unroll
+                for (int jp = 0; jp < 4; jp++) {
+                    const f2 a0 = from(0, jp), a1 = from(1, jp), a2 = from(2, jp), a3 = from(3, jp);
+                    const f2 b0 = from(0, 4 + jp), b1 = from(1, 4 + jp), b2 = from(2, 4 + jp), b3 = from(3, 4 + jp);
+                    // forward: (0,1), (2,3), then the two sums -- the oracle's recursion
+                    const f2 s01 = (a0 + a1) * HAAR_C, s23 = (a2 + a3) * HAAR_C;
+                    f2 d01 = (a0 - a1) * HAAR_C, d23 = (a2 - a3) * HAAR_C;
+                    f2 ss = (s01 + s23) * HAAR_C, dd = (s01 - s23) * HAAR_C;
+                    const f2 t01 = (b0 + b1) * HAAR_C, t23 = (b2 + b3) * HAAR_C;
+                    const f2 e01 = (b0 - b1) * HAAR_C, e23 = (b2 - b3) * HAAR_C;
+                    const f2 tt = (t01 + t23) * HAAR_C, ee = (t01 - t23) * HAAR_C;
+                    ss = wiener_w(tt, sigma2, sw) * ss;
+                    dd = wiener_w(ee, sigma2, sw) * dd;
+                    d01 = wiener_w(e01, sigma2, sw) * d01;
+                    d23 = wiener_w(e23, sigma2, sw) * d23;
+                    // inverse, my member only
+                    const f2 r01 = (ss + dd) * HAAR_C, r23 = (ss - dd) * HAAR_C;
+                    const f2 lo2 = member < 2 ? r01 : r23, de = member < 2 ? d01 : d23;
+                    top[jp] = (member & 1) ? (lo2 - de) * HAAR_C : (lo2 + de) * HAAR_C;
+                }
+            }
+            cbar();
+            raise_flag(sync + HNW + wave, seq, lane);          // my team mates may reuse their buffers
+        } else {
+#pragma unroll
+            for (int jp = 0; jp < 4; jp++) top[jp] = wiener_w(approx[4 + jp], sigma2, sw) * approx[jp];
+        }
+        quarter_unshrink_local<KQ>(S, top);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
+        const float w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
+        float ww[8];
+#pragma unroll
+        for (int y = 0; y < 8; y++) ww[y] = w * win_g[(hi * 8 + y) * 8 + lo];
+        if (lane >= kb && lane < kb + KQ) atomicAdd(cvol + (size_t)my_corner, w);
+
+        const int my_slot0 = (rz + my_dz + 5 + HNPL) % HNPL;
+        const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
+        // every team mate must have read my approximations before the inverse transposes overwrite them
+        if (K > 1) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (m < A && m != member) wait_flag(sync + HNW + team0 + m, seq, lane);
+        }
+        auto gate = [&](int k) {                   // per-block ring gate: see process_half_group
+            const int t = __builtin_amdgcn_readlane(my_dz, k) + 7;
+            const int need = layer + 1 - (HNPL - 5 - t + 3) / 4;
+            if (seen < need) {
+                cbar();
+                int v = 0;
+                if (lane == 0) {
+                    while ((v = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+                        __builtin_amdgcn_s_sleep(8);
+                }
+                seen = __builtin_amdgcn_readfirstlane(v);
+                cbar();
+            }
+        };
+        auto ring_off = [&](int k) -> int {
+            int slot = __builtin_amdgcn_readlane(my_slot0, k) + hi;
+            slot -= slot >= HNPL ? HNPL : 0;
+            return slot * HPS + __builtin_amdgcn_readlane(my_yx, k) + lo;
+        };
+        auto ring_add = [&](int off, const f2 (&v)[8], int comp) {
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+                __hip_atomic_fetch_add(ring + off + y * REG, (double)(ww[y] * (comp ? v[y].y : v[y].x)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if constexpr (KQ >= 4 && EXABM4D_X2INV) {
+            f2 w2[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v2[j] = mk2(S[j >> 1][(j & 1)], S[j >> 1][2 + (j & 1)]);
+                w2[j] = mk2(S[j >> 1][4 + (j & 1)], S[j >> 1][6 + (j & 1)]);
+            }
+            pair_inv_x2<false>(T, tb, hi, lo, v2, w2);
+            gate(kb);
+            ring_add(ring_off(kb), v2, 0);
+            gate(kb + 1);
+            ring_add(ring_off(kb + 1), v2, 1);
+            gate(kb + 2);
+            ring_add(ring_off(kb + 2), w2, 0);
+            gate(kb + 3);
+            ring_add(ring_off(kb + 3), w2, 1);
+        } else {
+#pragma unroll
+            for (int kl = 0; kl < KQ; kl += 2) {
+                constexpr bool two = KQ > 1;
+                const int kl2 = two ? kl + 1 : kl;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
+                pair_inv<false>(T, tb, hi, lo, v2);
+                gate(kb + kl);
+                ring_add(ring_off(kb + kl), v2, 0);
+                if constexpr (two) {
+                    gate(kb + kl2);
+                    ring_add(ring_off(kb + kl2), v2, 1);
+                }
+            }
+        }
+    };
+    if (active) {
+        switch (KQ) {
+            case 4: body(std::integral_constant<int, 4>{}); break;
+            case 2: body(std::integral_constant<int, 2>{}); break;
+            default: body(std::integral_constant<int, 1>{}); break;
+        }
+    } else {
+        // an idle member still reports, and like everybody else only once the layers whose planes
+        // this layer re-uses have been retired (see process_half_group)
+        if (lane == 0) {
+            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < layer - 2)
+                __builtin_amdgcn_s_sleep(8);
+        }
+        cbar();
+    }
+    const int closer = (__hip_atomic_fetch_add(cnt + (layer & (HNCNT - 1)), lane == 0 ? 1 : 0, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == target) ? 1 : 0;
+    return __builtin_amdgcn_readfirstlane(closer) != 0;
+}
+
+__global__ __launch_bounds__(QuadCfg::NW * 64) void stage_quad_kernel(
+    const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
+    const uint32_t* __restrict__ keys_all, VolGeom g, HalfTable T, const float* __restrict__ win_g,
+    float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x, int layers_per_chunk) {
+    using C = QuadCfg;
+    constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, HTY = C::TY, HTX = C::TX, NT = HNW / 4;
+    extern __shared__ __align__(16) float lds[];
+    ring_t* ring = reinterpret_cast<ring_t*>(lds);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * C::TBW);
+    f2* team_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + (wave & ~3) * C::TBW);
+    int* lock = reinterpret_cast<int*>(lds + 2 * HNPL * HPS + HNW * C::TBW);
+    int* sync = lock + 4;
+    int* cnt = sync + 2 * HNW;
+
+    const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
+    const float* __restrict__ noisy = noisy_all + voff;
+    const float* __restrict__ basic = basic_all + voff;
+    float* __restrict__ num = num_all + voff;
+    float* __restrict__ cvol = cvol_all + voff;
+    const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
+    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
+
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int iy0 = HTY * ty, ix0 = HTX * tx;
+    TileGeom tg;
+    tg.nry = min(HTY, g.gy - iy0);
+    tg.nrx = min(HTX, g.gx - ix0);
+    tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
+    tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
+    const int nrefs = tg.nry * tg.nrx;
+    const int izb = blockIdx.y * layers_per_chunk;
+    const int ize = min(g.gz, izb + layers_per_chunk);
+
+    for (int i = threadIdx.x; i < 2 * HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;
+    if (threadIdx.x < 4 + 2 * HNW + HNCNT) lock[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int teamid = wave >> 2;
+    int seq = 0, seen = 0;
+    const Dct7& tab = T;
+    for (int iz = izb; iz < ize; iz++) {
+        const int layer = iz - izb;
+        const int z0 = grid_pos(iz, g.az, g.nz);
+        // groups go round the teams, one team further every layer, while every team has a group in
+        // every layer (layers must complete in order: see stage_half_kernel)
+        const int rot = nrefs >= NT ? layer % NT : 0;
+        for (int r = (teamid + rot) % NT; r < nrefs; r += NT) {
+            const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
+            const int iy = iy0 + jy, ix = ix0 + jx;
+            const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
+            const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
+#if EXABM4D_PRIO
+            {
+                int f = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                f = __builtin_amdgcn_readfirstlane(f);
+                if (layer <= f)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
+#endif
+            const bool closer = process_quad_group(noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win_g, sigma2,
+                                                   ring, cvol, tb, team_tb, lock, sync, cnt, wave, seq, seen,
+                                                   layer, 4 * nrefs, lane, g.nvox);
+            if (closer) {
+                if (lane == 0)
+                    __hip_atomic_store(cnt + (layer & (HNCNT - 1)), 0, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) {
+                    while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != layer)
+                        __builtin_amdgcn_s_sleep(2);
+                }
+                cbar();
+                if (iz + 1 < ize) {
+                    const int zn = grid_pos(iz + 1, g.az, g.nz);
+                    for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane<C>(ring, num, z, tg, g, lane);
+                }
+                cbar();
+                if (lane == 0)
+                    __hip_atomic_store(lock + 1, layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                cbar();
+            }
+        }
+    }
+    __syncthreads();
+    if (ize > izb) {
+        const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
+        for (int z = base + wave; z < base + HNPL; z += HNW) flush_num_plane<C>(ring, num, z, tg, g, lane);
+    }
+}
+
+int g_stage_quads = EXABM4D_WIE_QUADS;   // exabm4d_set_option("stage_quads"): Wiener stage on teams of four waves
+
 constexpr int NW_HT = 4;
 constexpr int NW_WIE = 4;
 int g_stage_chunks = 0;      // exabm4d_set_option("stage_chunks"): z chunks of the stage kernels, 0 = automatic
@@ -1445,7 +1900,28 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
                                g, HT, win_dev, thr, sigma2, num, cwork, htx, hlpc);
             return hipGetLastError();
         };
-        e = basic ? launch(std::true_type{}) : launch(std::false_type{});
+        auto launch_quads = [&]() -> hipError_t {
+            using C = QuadCfg;
+            const int hty = (g.gy + C::TY - 1) / C::TY, htx = (g.gx + C::TX - 1) / C::TX;
+            const long long htiles = (long long)hty * htx * batch;
+            int hchunks = (int)((1024 + htiles - 1) / htiles);
+            const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
+            if (hchunks < fine) hchunks = fine;
+            if (g_stage_chunks > 0) hchunks = g_stage_chunks;
+            if (hchunks < 1) hchunks = 1;
+            if (hchunks > g.gz) hchunks = g.gz;
+            const int hlpc = (g.gz + hchunks - 1) / hchunks;
+            hchunks = (g.gz + hlpc - 1) / hlpc;
+            const dim3 hgrid((unsigned)(hty * htx), (unsigned)hchunks, (unsigned)batch);
+            const size_t lds = sizeof(float) * C::LDS_FLOATS;
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_quad_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return err;
+            hipLaunchKernelGGL(stage_quad_kernel, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys, g, HT,
+                               win_dev, sigma2, num, cwork, htx, hlpc);
+            return hipGetLastError();
+        };
+        e = basic ? (g_stage_quads ? launch_quads() : launch(std::true_type{})) : launch(std::false_type{});
         if (e != hipSuccess) return e;
         return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d,
                                        den_overwrite, stream);

@@ -393,3 +393,59 @@ def test_non_dyadic_offset_takes_the_float_kernel(ctx, oracle):
     from aind_exaspim_image_compression.distributed import offset_exact_in_fp32
     assert [offset_exact_in_fp32(o) for o in (0.0, 37.0, 100.5, 0.0078125, 36.73, 0.3, 70000.0)] == \
         [True, True, True, True, False, False, False]
+
+
+def test_quarter_group_wiener_kernel_equals_pairs_and_oracle(ctx, oracle):
+    """Round 3: the Wiener stage on teams of FOUR waves per group (stage_quad_kernel; groups of 16 /
+    8 / 4 give every member 4 / 2 / 1 blocks, groups of 2 and 1 leave members idle) against the
+    two-waves-per-group kernel and against the oracle: same match tables in, spectra bit-identical by
+    construction, estimates equal up to the order of the aggregation sums and of the weight
+    statistic.  A volume with every group size, tiles that march over several layers; then a tall
+    ragged one with edge tiles that hold fewer groups than the workgroup has teams."""
+    shape = (48, 384, 400)
+    noisy = _mixed_volume(shape, 31)
+    basic = (noisy + np.random.default_rng(5).normal(0, 2.0, shape)).astype(np.float32)   # any second volume will do
+    keys = _keys_gpu(ctx, basic, SIGMA, 0.6)
+    sizes = np.unique((keys != 0xFFFFFFFF).sum(axis=-1))
+    assert sizes.min() <= 1 and sizes.max() == 16
+    res = {}
+    try:
+        for quads in (1, 0):
+            ctx.set_option("stage_quads", quads)
+            res[quads] = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic)
+    finally:
+        ctx.set_option("stage_quads", 1)
+    (num1, den1), (num0, den0) = res[1], res[0]
+    assert np.all(den1 > 0)
+    np.testing.assert_allclose(den1, den0, rtol=2e-5)
+    _assert_close_estimates(num1 / den1, num0 / den0, SIGMA)
+    sub = (slice(0, 32), slice(100, 148), slice(60, 108))       # oracle on a crop across the regimes
+    cn, cb = np.ascontiguousarray(noisy[sub]), np.ascontiguousarray(basic[sub])
+    kc = oracle.blockmatch(cb, SIGMA, 0.6)
+    num_w, den_w = oracle.stage(cn, kc, SIGMA, basic=cb)
+    num_g, den_g = _stage_gpu(ctx, cn, kc, SIGMA, basic=cb)
+    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    # tall + ragged, one z chunk, both stages through the uint16 pipeline
+    import bench
+    shape = (253, 61, 57)
+    vol = bench.synth_u16(shape, 7)
+    vol[:40] = 0
+    vol[:, :, -9:] = 0
+    d_in, d_out = ctx.to_device(vol), ctx.alloc(vol.nbytes)
+    outs = []
+    ctx.set_option("stage_chunks", 1)
+    try:
+        for quads in (1, 0, 1):
+            ctx.set_option("stage_quads", quads)
+            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0, stages=2)
+            ctx.sync()
+            outs.append(d_out.download(shape, np.uint16).astype(np.int32))
+    finally:
+        ctx.set_option("stage_quads", 1)
+        ctx.set_option("stage_chunks", 0)
+        d_in.free()
+        d_out.free()
+    for a in (outs[0], outs[2]):
+        d = np.abs(a - outs[1])
+        assert d.max() <= 1 and np.mean(d > 0) < 5e-3, (int(d.max()), int((d > 1).sum()))
