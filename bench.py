@@ -808,8 +808,9 @@ def main():
                 "delta_db": psnr_db(gpu256, clean, peak) - psnr_db(port256, clean, peak),
                 "gpu_vs_cpu": psnr_db(gpu256, port256, peak),
                 "max_abs_u16": int(d.max()), "frac_differing": float(np.mean(d > 0)),
-                # beyond the one count a rounding tie costs: relative to the estimate itself
-                "max_rel_diff": float(np.max(np.where(d > 1, d / np.maximum(port256.astype(np.float64), 1.0), 0.0))),
+                # more than the one count of a rounding tie: voxels whose stage-2 group changed because the
+                # last bits of the basic estimate moved a match table (tests/test_pipeline_differences_gpu.py)
+                "frac_beyond_one_count": float(np.mean(d > 1)),
             }
         if args.bm4dnet > 0 and world == 1:
             # BASELINE config 3's learned stage, after the timed region and outside `value`
