@@ -1407,8 +1407,12 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
 // Groups of 8 / 4 blocks give every member 2 / 1; a group of 2 occupies two members, a group of 1
 // one; the others idle through it (and still report to the layer counter).
 // =================================================================================================
+// MEASURED (round 3, one box, A/B/A/B at 1024^3): 293 ms against 228 ms for the two-waves-per-group
+// kernel -- the third wave per SIMD does not pay for the second exchange round, the redundant top
+// levels, 23 spilled registers at the 168-register cap and the 8-groups-on-3-teams imbalance.  Kept as
+// an option (exabm4d_set_option("stage_quads", 1), parity-tested), OFF by default.  DESIGN.md 5.2i.
 #ifndef EXABM4D_WIE_QUADS
-#define EXABM4D_WIE_QUADS 1                    // 0: the Wiener stage runs the two-waves-per-group kernel
+#define EXABM4D_WIE_QUADS 0                    // 1: the Wiener stage runs on teams of four waves by default
 #endif
 #ifndef EXABM4D_QUAD_NW
 #define EXABM4D_QUAD_NW 12
