@@ -22,8 +22,10 @@ PHASES = {           # bench phase -> (kernel-name fragment, launches of it per 
     "stage_wie": "stage_half_kernel<true>",
     "normalize_basic": "normalize_kernel",
     "normalize_out": "OpNormalizeU16",
-    "encode_u16": "rans_encode_kernel<2,",
-    "encode_idx": "rans_encode_kernel<4,",
+    # EXAC v2 legs are three kernels each (model, coder, pack; the pack kernel serves both legs, so its
+    # per-launch mean is the mean over the two): time and counters are summed over the fragments
+    "encode_u16": ["rans2_model_strips_kernel", "rans2_code_kernel<2>", "rans2_pack_kernel"],
+    "encode_idx": ["rans2_model_rows32_kernel", "rans2_code_kernel<4>", "rans2_pack_kernel"],
     "dct_quantise": "dctq_forward",
 }
 
@@ -55,17 +57,21 @@ def main():
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
                             cwd=os.path.dirname(HERE)).stdout.strip()
     kernels = {}
-    for phase, frag in PHASES.items():
-        name = next((k for k in pmc if frag in k), None)
-        tname = next((k for k in avg if frag in k), None)
-        if name is None and tname is None:
+    for phase, frags in PHASES.items():
+        frags = [frags] if isinstance(frags, str) else list(frags)
+        names = [next((k for k in pmc if f in k), None) for f in frags]
+        tnames = [next((k for k in avg if f in k), None) for f in frags]
+        if all(n is None for n in names) and all(t is None for t in tnames):
             continue
-        c = pmc.get(name, {})
 
         def val(counter):
-            return c[counter]["per_launch_mean"] if counter in c else None
+            got = [pmc[n][counter]["per_launch_mean"] for n in names if n and counter in pmc.get(n, {})]
+            return sum(got) if len(got) == len([n for n in names if n]) and got else None
 
-        rec = {"kernel": name or tname, "avg_ms": avg.get(tname)}
+        rec = {"kernel": " + ".join(n or t or "?" for n, t in zip(names, tnames)),
+               "avg_ms": sum(avg[t] for t in tnames if t) if any(tnames) else None}
+        if len(frags) > 1:
+            rec["parts_ms"] = {t: avg[t] for t in tnames if t}
         if val("FETCH_SIZE") is not None and val("WRITE_SIZE") is not None:
             rec["hbm_bytes"] = (2.0 * val("FETCH_SIZE") + val("WRITE_SIZE")) * 1024.0
         if val("SQ_INSTS_VALU") is not None:
