@@ -504,6 +504,125 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_xy4_kernel(const float* __re
     }
 }
 
+// The z pass of the denominator convolution fused into the normalisation (round 3): a thread owns W
+// consecutive x of one (volume, y) line and marches along z with the 8-deep shift register of
+// conv8_line_kernel -- den = the same fmaf chain, in the same order -- then out = num / den (+ clip,
+// or + offset, clamp, rint, uint16).  Saves the pass that wrote den and the one that read it back
+// (8 B per voxel and stage); results are bit-identical to the two-kernel form.
+template <int W, bool U16>
+__global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float* __restrict__ num,
+                                                                     const float* __restrict__ txy,
+                                                                     void* __restrict__ out, size_t nlines,
+                                                                     size_t plane, int nz, Win1D w, float lo,
+                                                                     float hi, int do_clip, float offset) {
+    const size_t lines_per_vol = plane / W;
+    for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
+         l += (size_t)gridDim.x * EW_THREADS) {
+        const size_t o = l / lines_per_vol, i = l - o * lines_per_vol;
+        const size_t base = o * (size_t)nz * plane + (size_t)W * i;
+        float h[8][W];
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int j = 0; j < W; j++) h[t][j] = 0.0f;
+        for (int z = 0; z < nz; z++) {
+            const size_t at = base + (size_t)z * plane;
+#pragma unroll
+            for (int t = 7; t > 0; t--)
+#pragma unroll
+                for (int j = 0; j < W; j++) h[t][j] = h[t - 1][j];
+            float a[W];
+            if (W == 4) {
+                const float4 c = *reinterpret_cast<const float4*>(txy + at);
+                const float4 m = *reinterpret_cast<const float4*>(num + at);
+                h[0][0] = c.x; h[0][1 % W] = c.y; h[0][2 % W] = c.z; h[0][3 % W] = c.w;
+                a[0] = m.x; a[1 % W] = m.y; a[2 % W] = m.z; a[3 % W] = m.w;
+            } else {
+                h[0][0] = txy[at];
+                a[0] = num[at];
+            }
+            float r[W];
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                float den = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 8; t++) den = fmaf(w.k[t], h[t][j], den);
+                r[j] = a[j] / den;
+            }
+            if (U16) {
+                uint16_t* o16 = static_cast<uint16_t*>(out) + at;
+                if (W == 4) {
+                    const uint32_t q0 = quantise_u16(r[0] + offset, 65535.0f), q1 = quantise_u16(r[1 % W] + offset, 65535.0f);
+                    const uint32_t q2 = quantise_u16(r[2 % W] + offset, 65535.0f), q3 = quantise_u16(r[3 % W] + offset, 65535.0f);
+                    *reinterpret_cast<uint2*>(o16) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+                } else {
+                    o16[0] = quantise_u16(r[0] + offset, 65535.0f);
+                }
+            } else {
+                float* o32 = static_cast<float*>(out) + at;
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    if (do_clip) r[j] = fminf(fmaxf(r[j], lo), hi);
+                if (W == 4)
+                    *reinterpret_cast<float4*>(o32) = make_float4(r[0], r[1 % W], r[2 % W], r[3 % W]);
+                else
+                    o32[0] = r[0];
+            }
+        }
+    }
+}
+
+// den's x / y passes only (C -> tmp); the z pass then rides with the normalisation (launch_normalize_zconv)
+hipError_t launch_den_xy_from_corners(float* C, float* tmp, int nz, int ny, int nx, int batch, const float* win1d,
+                                      hipStream_t s) {
+    Win1D w;
+    for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
+    auto blocks = [](size_t items) {
+        size_t b = (items + EW_THREADS - 1) / EW_THREADS;
+        if (b > 65536) b = 65536;
+        return dim3((unsigned)(b ? b : 1));
+    };
+    if (nx % 4 == 0 && ((uintptr_t)C & 15u) == 0 && ((uintptr_t)tmp & 15u) == 0) {
+        const size_t lines4 = (size_t)batch * nz * (nx / 4);
+        hipLaunchKernelGGL(conv8_xy4_kernel, blocks(lines4), dim3(EW_THREADS), 0, s, C, tmp, lines4, nx / 4, ny, w);
+    } else {
+        const size_t ylines = (size_t)batch * nz * nx;
+        hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp, ylines,
+                           (size_t)nx, ny, w);
+    }
+    return hipGetLastError();
+}
+
+// out = num / (txy (*)_z win): exactly one of out_f32 / out_u16
+hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out_f32, uint16_t* out_u16, int nz,
+                                  int ny, int nx, int batch, const float* win1d, float lo, float hi, float offset,
+                                  hipStream_t s) {
+    Win1D w;
+    for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
+    const size_t plane = (size_t)ny * nx;
+    void* out = out_u16 ? static_cast<void*>(out_u16) : static_cast<void*>(out_f32);
+    const bool wide = plane % 4 == 0 && ((uintptr_t)num & 15u) == 0 && ((uintptr_t)txy & 15u) == 0 &&
+                      ((uintptr_t)out & 15u) == 0 && ((size_t)nz * plane) % 4 == 0;
+    const size_t nlines = (size_t)batch * (wide ? plane / 4 : plane);
+    size_t b = (nlines + EW_THREADS - 1) / EW_THREADS;
+    if (b > 65536) b = 65536;
+    const dim3 grid((unsigned)(b ? b : 1));
+    const int clip = lo <= hi ? 1 : 0;
+    if (wide && out_u16)
+        hipLaunchKernelGGL((normalize_zconv_kernel<4, true>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines, plane,
+                           nz, w, lo, hi, clip, offset);
+    else if (wide)
+        hipLaunchKernelGGL((normalize_zconv_kernel<4, false>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines,
+                           plane, nz, w, lo, hi, clip, offset);
+    else if (out_u16)
+        hipLaunchKernelGGL((normalize_zconv_kernel<1, true>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines, plane,
+                           nz, w, lo, hi, clip, offset);
+    else
+        hipLaunchKernelGGL((normalize_zconv_kernel<1, false>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines,
+                           plane, nz, w, lo, hi, clip, offset);
+    return hipGetLastError();
+}
+
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
                                    const float* win1d, int overwrite, hipStream_t s) {
     Win1D w;

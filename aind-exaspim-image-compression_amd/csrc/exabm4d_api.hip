@@ -38,6 +38,7 @@ struct exabm4d_ctx {
     int profile = 0;           // exabm4d_set_option("profile")
     int bm_int = 1;            // exabm4d_set_option("bm_int"): integer block matching on uint16 input
     int codec_version = 2;     // exabm4d_set_option("codec_version"): stream format the encoder writes
+    int fuse_den_z = 1;        // exabm4d_set_option("fuse_den_z"): z pass of the denominator inside the normalisation
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
@@ -317,6 +318,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     }
     if (std::strcmp(name, "stage_pairs") == 0) {
         ctx->stage_pairs = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "fuse_den_z") == 0) {
+        ctx->fuse_den_z = value ? 1 : 0;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "codec_version") == 0) {
@@ -617,6 +622,10 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
     hipStream_t s = ctx->stream;
+    // two-waves-per-group kernels: den = C (*) win; its z pass is fused into the normalisation kernels
+    // (cwork + n holds the x / y passes' result), unless the option asks for the separate pass
+    const bool fused = ctx->stage_pairs && ctx->fuse_den_z;
+    const int den_mode = fused ? 2 : ctx->stage_pairs;
     if (ctx->profile)
         for (int i = 1; i < EXABM4D_PHASE_COUNT; i++) ctx->ev_used[i] = false;
     if ((noisy_guarded && !guarded_region_ok(ctx, noisy, n * sizeof(float))) ||
@@ -642,13 +651,16 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
         HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                  sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork,
-                                  ctx->stage_pairs));
+                                  sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode));
     }
     if (stages >= 2) {
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_BASIC);
-            HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
+            if (fused)
+                HIP_TRY(ctx, launch_normalize_zconv(num, cwork + n, basic, nullptr, g.nz, g.ny, g.nx, batch,
+                                                    ctx->win1d, 1.0f, 0.0f, 0.0f, s));
+            else
+                HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_2);
@@ -663,13 +675,15 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
             HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork,
-                                  ctx->stage_pairs));
+                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode));
         }
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_OUT);
-        if (out_u16)
+        if (fused)
+            HIP_TRY(ctx, launch_normalize_zconv(num, cwork + n, out_f32, out_u16, g.nz, g.ny, g.nx, batch,
+                                                ctx->win1d, clip_lo, clip_hi, u16_offset, s));
+        else if (out_u16)
             HIP_TRY(ctx, launch_normalize_u16(num, den, out_u16, n, u16_offset, s));
         else
             HIP_TRY(ctx, launch_normalize(num, den, out_f32, n, clip_lo, clip_hi, s));

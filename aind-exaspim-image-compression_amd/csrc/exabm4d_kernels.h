@@ -69,6 +69,14 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
 // den += conv(tmp) (den = conv(tmp) with `overwrite`: the caller need not zero den first).
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
                                    const float* win1d, int overwrite, hipStream_t s);
+// The pipelines' form (launch_stage with den_overwrite == 2): only the x / y passes run after the
+// stage kernel (C -> tmp = cwork + n) and the z pass rides with the normalisation:
+// out = num / (tmp (*)_z win), then clip (f32) or + offset, clamp, rint (uint16).
+hipError_t launch_den_xy_from_corners(float* C, float* tmp, int nz, int ny, int nx, int batch, const float* win1d,
+                                      hipStream_t s);
+hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out_f32, uint16_t* out_u16, int nz,
+                                  int ny, int nx, int batch, const float* win1d, float lo, float hi, float offset,
+                                  hipStream_t s);
 
 // ---- chunk-local mode (elementwise_kernels.hip) ------------------------------------------------------
 // One batch of equally shaped padded chunks out of a sub-grid of chunks (sgz x sgy x sgx chunks

@@ -1927,6 +1927,8 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
         };
         e = basic ? (g_stage_quads ? launch_quads() : launch(std::true_type{})) : launch(std::false_type{});
         if (e != hipSuccess) return e;
+        if (den_overwrite == 2)       // the pipelines fuse the z pass into their normalisation kernel
+            return launch_den_xy_from_corners(cwork, cwork + n, g.nz, g.ny, g.nx, batch, win1d, stream);
         return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d,
                                        den_overwrite, stream);
     } else if (basic) {

@@ -455,3 +455,33 @@ def test_quarter_group_wiener_kernel_equals_pairs_and_oracle(ctx, oracle):
     for a in (outs[0], outs[2]):
         d = np.abs(a - outs[1])
         assert d.max() <= 1 and np.mean(d > 0) < 5e-3, (int(d.max()), int((d > 1).sum()))
+
+
+@pytest.mark.parametrize("shape", [(40, 44, 48), (24, 31, 37), (16, 20, 22)])
+def test_fused_denominator_z_pass_is_bit_identical(ctx, shape):
+    """Round 3: the z pass of the denominator convolution rides with the normalisation kernels
+    (normalize_zconv_kernel: same 8-tap fmaf chain, then num / den) instead of writing den and
+    reading it back.  Bit-identical to the separate passes, for the fp32 and the uint16 pipelines,
+    rows that are multiples of four (float4 lanes) and rows that are not (scalar lanes), both stages."""
+    vol16 = synth_volume(shape, seed=sum(shape), as_u16=True)[0]
+    volf = vol16.astype(np.float32) - np.float32(37.0)
+    outs = {}
+    try:
+        for fuse in (1, 0):
+            ctx.set_option("fuse_den_z", fuse)
+            d_in, d_out = ctx.to_device(vol16), ctx.alloc(vol16.nbytes)
+            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0)
+            ctx.sync()
+            u = d_out.download(shape, np.uint16)
+            d_in.free()
+            d_out.free()
+            outs[fuse] = (u, ctx.denoise_f32_host(volf, SIGMA, stages=1),
+                          ctx.denoise_f32_host(volf, SIGMA, stages=2, clip=(0.0, 500.0)))
+    finally:
+        ctx.set_option("fuse_den_z", 1)
+    # stage 1 alone: the kernels run on the same inputs, only the aggregation's arrival order varies
+    # between launches, so compare at the tolerance of two runs of the SAME configuration
+    for a, b in zip(outs[1], outs[0]):
+        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        assert d.max() <= (1 if a.dtype == np.uint16 else 0.05), float(d.max())
+        assert np.mean(d > 0) < (2e-3 if a.dtype == np.uint16 else 1.0)
