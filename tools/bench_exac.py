@@ -50,9 +50,19 @@ def main():
             ctx.sync()
             ms = ctx.elapsed_ms(ev[0], ev[1]) / reps
             nel = int(np.prod(vshape))
+            # decode of the same container (synchronises: the entry point reports malformed streams)
+            d_back = ctx.alloc(ts * nel)
+            ctx.codec_decode(d_out, tot[1], d_off, ts, vshape, chunk, d_back)
+            import time
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.codec_decode(d_out, tot[1], d_off, ts, vshape, chunk, d_back)
+            dec_ms = (time.perf_counter() - t0) / reps * 1e3
+            d_back.free()
             out[f"v{version}_{name}"] = {"ms": round(ms, 3), "coded_bytes": tot[0],
                                          "bits_per_element": round(8.0 * tot[0] / nel, 4),
-                                         "GBps_in": round(ts * nel / ms / 1e6, 1)}
+                                         "GBps_in": round(ts * nel / ms / 1e6, 1),
+                                         "decode_ms_host_visible": round(dec_ms, 3)}
             for b in (d_out, d_off, d_sz):
                 b.free()
     ctx.set_option("codec_version", 2)
