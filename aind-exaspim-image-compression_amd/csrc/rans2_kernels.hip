@@ -10,6 +10,8 @@
 // Integer work only.  One workgroup = one chunk = one wave: pass 1 counts (context, symbol) pairs in
 // LDS, the wave turns the 16 histograms into tables (lane = symbol), pass 2 walks the rows from the
 // last to the first and appends renormalisation words with a ballot + mbcnt rank.
+#include <algorithm>
+
 #include "exabm4d_kernels.h"
 #include "rans_common.h"
 
@@ -22,7 +24,7 @@ constexpr uint32_t TAP_LIMIT = 8000u;     // largest tap distance (elements) the
 constexpr int HDR2 = 276;                 // magic, n, ey, ex, nwords, present[16], wide[16]
 constexpr int TAB2_MAX = NCTX * NSYM * 2;
 constexpr int SLOT2_TABLEN = HDR2 + TAB2_MAX;          // u32: table bytes of the chunk (scratch only)
-constexpr uint32_t RING = 8192u;          // decoder history (elements); >= TAP_LIMIT + 2 * 64
+constexpr uint32_t RING_MAX = 8192u;      // decoder history (elements) at most: >= TAP_LIMIT + 2 * 64
 
 // activity -> context: number of edges {1,2,3,4,5,6,8,10,13,17,22,30,45,70,120} that are <= a
 __device__ __forceinline__ uint32_t ctx_of_activity(uint32_t a) {
@@ -618,10 +620,15 @@ template <int TS>
 __global__ __launch_bounds__(64) void rans2_decode_kernel(const uint8_t* __restrict__ in, size_t in_bytes,
                                                           const unsigned long long* __restrict__ offsets,
                                                           CodecGeom g, void* __restrict__ vol,
-                                                          uint32_t* __restrict__ status) {
-    __shared__ uint16_t cum[NCTX * (NSYM + 1)];
-    __shared__ uint8_t mring[RING];
-    __shared__ uint16_t vring[TS == 2 ? RING : 1];
+                                                          uint32_t* __restrict__ status, uint32_t ring) {
+    // History ring of `ring` elements (a multiple of 64 that covers the farthest tap of any chunk of
+    // this volume plus the row being written: decode_ring_elems): magnitudes, and for uint16 the
+    // values.  Sized per launch -- 4224 elements for 64^3 chunks instead of a fixed 8192 -- because
+    // LDS is what limits the resident waves of this one-wave-per-chunk kernel.
+    extern __shared__ __align__(16) uint8_t dyn_lds[];
+    uint16_t* cum = reinterpret_cast<uint16_t*>(dyn_lds);
+    uint16_t* vring = cum + ((NCTX * (NSYM + 1) + 7) & ~7);
+    uint8_t* mring = reinterpret_cast<uint8_t*>(vring + (TS == 2 ? ring : 0));
     const int c = blockIdx.x;
     const uint32_t lane = lane_id();
     const ChunkBox b = chunk_box(g, c);
@@ -713,7 +720,8 @@ __global__ __launch_bounds__(64) void rans2_decode_kernel(const uint8_t* __restr
         if (need) x = (x << 16) | words[cursor + rank_below(nm)];
         return true;
     };
-    for (uint32_t r = 0; r < rows; r++) {
+    uint32_t rbase = 0;
+    for (uint32_t r = 0; r < rows; r++, rbase = rbase + 64u >= ring ? 0u : rbase + 64u) {
         const uint32_t i = r * 64u + lane;
         const bool act = i < n;
         RowPos p;
@@ -728,7 +736,12 @@ __global__ __launch_bounds__(64) void rans2_decode_kernel(const uint8_t* __restr
         bool U, B;
         uint32_t ku, kb;
         t.flags(i, p.z, p.y, act, U, B, ku, kb);
-        const uint32_t ju = (i - ku * t.ex) & (RING - 1u), jb = (i - kb * t.plane) & (RING - 1u);
+        // ring slots: this row starts at `rbase` (= 64 r mod ring, kept incrementally), a tap lies
+        // its distance back (distances of used taps are < ring - 64)
+        const uint32_t slot_i = rbase + lane;
+        const uint32_t du = ku * t.ex, db = kb * t.plane;
+        const uint32_t ju = U ? (slot_i >= du ? slot_i - du : slot_i + ring - du) : 0u;
+        const uint32_t jb = B ? (slot_i >= db ? slot_i - db : slot_i + ring - db) : 0u;
         const uint32_t mu = U ? mring[ju] : 0u, mb = B ? mring[jb] : 0u;
         const uint32_t a = U && B ? mu + mb : (U ? 2u * mu : (B ? 2u * mb : 0u));
         const uint32_t q = ctx_of_activity(a);
@@ -791,12 +804,12 @@ __global__ __launch_bounds__(64) void rans2_decode_kernel(const uint8_t* __restr
                 }
             }
             const uint32_t u32 = (uint32_t)u;
-            mring[i & (RING - 1u)] = (uint8_t)mag_of(u32);
+            mring[slot_i] = (uint8_t)mag_of(u32);
             const size_t off = (size_t)p.z * t.sz + (size_t)p.y * t.sy + p.x;
             if (TS == 2) {
                 const uint32_t r16 = (u32 >> 1) ^ (0u - (u32 & 1u));
                 const uint16_t v = (uint16_t)(pred + r16);
-                vring[i & (RING - 1u)] = v;
+                vring[slot_i] = v;
                 static_cast<uint16_t*>(vol)[b.base + off] = v;
             } else {
                 static_cast<int32_t*>(vol)[b.base + off] = (int32_t)((u32 >> 1) ^ (0u - (u32 & 1u)));
@@ -876,14 +889,37 @@ hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32
     return hipGetLastError();
 }
 
+// elements of decoder history a volume's chunks need: the farthest tap any lane of any chunk uses
+// (multiples of ex / ey * ex up to TAP_LIMIT; for rows or planes narrower than a wave up to 64 more)
+// plus the row being written, as a multiple of 64
+static uint32_t decode_ring_elems(const CodecGeom& g) {
+    auto reach = [](size_t stride) -> size_t {
+        if (stride > TAP_LIMIT) return 0;
+        return stride >= 64 ? stride : ((63 / stride) + 1) * stride;      // k = lane / stride + 1, lane <= 63
+    };
+    // edge chunks are smaller than (cy, cx): take the largest reach over the extents that occur
+    size_t far = 0;
+    const int exs[2] = {g.cx, g.nx % g.cx ? g.nx % g.cx : g.cx};
+    const int eys[2] = {g.cy, g.ny % g.cy ? g.ny % g.cy : g.cy};
+    for (int a = 0; a < 2; a++) {
+        far = std::max(far, reach((size_t)exs[a]));
+        for (int b = 0; b < 2; b++) far = std::max(far, reach((size_t)exs[a] * eys[b]));
+    }
+    size_t ring = ((far + 64 + 63) / 64) * 64;
+    if (ring > RING_MAX) ring = RING_MAX;
+    return (uint32_t)ring;
+}
+
 hipError_t launch_rans2_decode(const uint8_t* in, size_t in_bytes, const unsigned long long* offsets,
                                const CodecGeom& g, void* vol, uint32_t* status, hipStream_t s) {
+    const uint32_t ring = decode_ring_elems(g);
+    const size_t lds = 2 * (size_t)((NCTX * (NSYM + 1) + 7) & ~7) + (g.ts == 2 ? 2 * (size_t)ring : 0) + ring;
     if (g.ts == 2)
-        hipLaunchKernelGGL(rans2_decode_kernel<2>, dim3((unsigned)g.nchunks), dim3(64), 0, s, in, in_bytes, offsets,
-                           g, vol, status);
+        hipLaunchKernelGGL(rans2_decode_kernel<2>, dim3((unsigned)g.nchunks), dim3(64), lds, s, in, in_bytes, offsets,
+                           g, vol, status, ring);
     else
-        hipLaunchKernelGGL(rans2_decode_kernel<4>, dim3((unsigned)g.nchunks), dim3(64), 0, s, in, in_bytes, offsets,
-                           g, vol, status);
+        hipLaunchKernelGGL(rans2_decode_kernel<4>, dim3((unsigned)g.nchunks), dim3(64), lds, s, in, in_bytes, offsets,
+                           g, vol, status, ring);
     return hipGetLastError();
 }
 
