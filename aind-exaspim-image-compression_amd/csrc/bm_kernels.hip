@@ -57,9 +57,6 @@ struct TileShape {
 // 1.8 TB of fabric traffic per 1024^3 launch at 7 TB/s -- bandwidth-bound on re-reads).
 // The cell-sum exchange buffer aliases the waves' current plane buffers (each wave publishes the
 // sums of its own 64 cells in its own buffer once its reads of the plane are done).
-#ifndef EXABM4D_BM_TWO_BODIES
-#define EXABM4D_BM_TWO_BODIES 1
-#endif
 template <class TS>
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
@@ -176,17 +173,23 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     else
         stage_edge(0, pbuf_all[cz][0]);
 
-    // One step = one staged plane.  EXABM4D_BM_TWO_BODIES: the first pass of a dz covers dy = -5..0 (six
-    // rows of sums), the second dy = 1..5 (five) -- the body is instantiated for both counts, so no
-    // cycles go into a twelfth, masked dy (as in bm_tile16_kernel).
-    // common head of a step: wait for the plane, load the cell's own plane, start the next plane
-    float A[16];
-    auto step_head = [&](const int step) {
-        const int z = step & 3;
+    float acc[NE][SWIN];
+#pragma unroll
+    for (int e = 0; e < NE; e++)
+#pragma unroll
+        for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
+
+#pragma unroll 1
+    for (int step = 0; step < NSTEP; step++) {
+        const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
+        const int dylo = pass == 0 ? -RAD : 1;
+        float* cur = pbuf_all[cz][step & 1];
         float* nxt = pbuf_all[cz][(step + 1) & 1];
+
         // this step's plane has landed (DMA counts in vmcnt) ...
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // own cell plane z (16 values; L1-resident after the first pass)
+        float A[16];
 #pragma unroll
         for (int y = 0; y < 4; y++) {
             const float4u t4 = *reinterpret_cast<const float4u*>(
@@ -201,31 +204,18 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
         // (conditional) DMA block, which would expose the whole DMA latency every step.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (xin && step + 1 < NSTEP) issue_dma(step + 1, nxt);
-    };
-    // `acc`: the pass's NEP x 11 accumulators, owned by the pass loop below (a pass = four steps)
-    auto step_body = [&](auto NEc, const int step, auto& acc) {
-        constexpr int NEP = decltype(NEc)::value;                 // dy values of this pass
-        constexpr int NR0 = (NEP + 1) / 2;                        // ... of its first exchange round
-        const int z = step & 3, dz = (step >> 3) - RAD;
-        const int dylo = ((step >> 2) & 1) == 0 ? -RAD : 1;
-        float* cur = pbuf_all[cz][step & 1];
-        float* nxt = pbuf_all[cz][(step + 1) & 1];
-        // lane-derived offsets are recomputed per step on purpose: left loop-invariant, hipcc hoists the
-        // LDS addresses of BOTH bodies out of the step loop and spills thirty registers
-        int lcx = cx, lcy = cy, llane = lane;
-        asm volatile("" : "+v"(lcx), "+v"(lcy), "+v"(llane));
 
         // ---- accumulate: row rp = y + e of the cell's window -----------------------------------
         {
-            const float* wrow = cur + (4 * lcy) * PSTR + 4 * lcx;
+            const float* wrow = cur + (4 * cy) * PSTR + 4 * cx;
             float4 wq[4], wn[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) wq[j] = *reinterpret_cast<const float4*>(wrow + 4 * j);
 #pragma unroll
-            for (int rp = 0; rp < 3 + NEP; rp++) {
+            for (int rp = 0; rp < 3 + NE; rp++) {
                 // one-row lookahead; the fence keeps hipcc from hoisting all nine rows' loads
                 // (and their 144 registers) to the top of the plane
-                if (rp + 1 < 3 + NEP) {
+                if (rp + 1 < 3 + NE) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         wn[j] = *reinterpret_cast<const float4*>(wrow + (rp + 1) * PSTR + 4 * j);
@@ -237,7 +227,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int y = 0; y < 4; y++) {
                     const int e = rp - y;
-                    if (e >= 0 && e < NEP) {
+                    if (e >= 0 && e < NE) {
 #pragma unroll
                         for (int x = 0; x < 4; x++) {
                             const float a = A[4 * y + x];
@@ -259,18 +249,17 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             // ---- cell sums -> LDS -> reference lanes: combine 8 cells, build keys, top-16 ------
             // exchange slot of cell (wave w, local l), displacement d: pbuf_all[w][cur][64 d + l]
             const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
-            float* mine = cur + llane;
-            const float* lo_w = cur + llane;                                 // cells of wave cz
-            const float* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + llane;  // wave cz + 1
+            float* mine = cur + lane;
+            const float* lo_w = cur + lane;                                  // cells of wave cz
+            const float* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;  // wave cz + 1
             // NE / 2 dy values per round (33 sums per cell fit the 36 slots of a plane buffer):
             // two barrier pairs per pass instead of six.  Each cell lane first adds its
             // x-neighbour's sum (DPP row_shl:1, no LDS), so a reference lane reads 4 values per
             // candidate instead of 8: S = ((c000+c001)+(c010+c011)) + ((c100+c101)+(c110+c111)).
 #pragma unroll
-            for (int rnd = 0; rnd < 2; rnd++) {
-                const int e0 = rnd ? NR0 : 0, e1 = rnd ? NEP : NR0;
+            for (int e0 = 0; e0 < NE; e0 += NE / 2) {
 #pragma unroll
-                for (int e = e0; e < e1; e++)
+                for (int e = e0; e < e0 + NE / 2; e++)
 #pragma unroll
                     for (int d = 0; d < SWIN; d++) {
                         const float right = __int_as_float(__builtin_amdgcn_update_dpp(
@@ -280,7 +269,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                 __syncthreads();
                 if (ref_ok) {
 #pragma unroll
-                    for (int e = e0; e < e1; e++) {
+                    for (int e = e0; e < e0 + NE / 2; e++) {
                         const int dy = dylo + e;
                         if (dy <= RAD) {                   // dy = 6 of the second pass is a dummy
                             const bool vzy = vz && (ry + dy >= 0) && (ry + dy <= g.ny - BLK);
@@ -314,34 +303,14 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                 }
                 __syncthreads();
             }
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+#pragma unroll
+                for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
         }
 
         // edge tiles stage the next plane synchronously (all reads of `nxt` are long done)
         if (!xin && step + 1 < NSTEP) stage_edge(step + 1, nxt);
-    };
-    // a pass = four steps (the four z planes of the cells) into one set of accumulators, declared
-    // inside the pass so that the sets of the two bodies never live at the same time
-    auto run_pass = [&](auto NEc, const int step0) {
-        constexpr int NEP = decltype(NEc)::value;
-        float acc[NEP][SWIN];
-#pragma unroll
-        for (int e = 0; e < NEP; e++)
-#pragma unroll
-            for (int d = 0; d < SWIN; d++) acc[e][d] = 0.0f;
-#pragma unroll 1
-        for (int step = step0; step < step0 + 4; step++) {
-            step_head(step);
-            step_body(NEc, step, acc);
-        }
-    };
-#pragma unroll 1
-    for (int s8 = 0; s8 < NSTEP; s8 += 8) {          // one dz: dy = -5..0, then dy = 1..5
-        run_pass(std::integral_constant<int, NE>{}, s8);
-#if EXABM4D_BM_TWO_BODIES
-        run_pass(std::integral_constant<int, NE - 1>{}, s8 + 4);
-#else
-        run_pass(std::integral_constant<int, NE>{}, s8 + 4);
-#endif
     }
 
     if (ref_ok) {
