@@ -20,8 +20,9 @@ PHASES = {           # bench phase -> (kernel-name fragment, launches of it per 
     "blockmatch_wie": "bm_tile_kernel",
     "stage_ht": "stage_half_kernel<false>",
     "stage_wie": "stage_half_kernel<true>",
-    "normalize_basic": "normalize_kernel",
-    "normalize_out": "OpNormalizeU16",
+    # (round 3: the pipelines' normalisations carry the z pass of the denominator convolution)
+    "normalize_basic": "normalize_zconv_kernel<4, false>",
+    "normalize_out": "normalize_zconv_kernel<4, true>",
     # EXAC v2 legs are three kernels each (model, coder, pack; the pack kernel serves both legs, so its
     # per-launch mean is the mean over the two): time and counters are summed over the fragments
     "encode_u16": ["rans2_model_strips_kernel", "rans2_code_kernel<2>", "rans2_pack_kernel"],
