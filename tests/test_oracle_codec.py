@@ -278,3 +278,31 @@ def test_v2_malformed_streams_are_rejected():
     bad[16:20] = (1 << 30).to_bytes(4, "little")               # more words than the stream holds
     with pytest.raises(ValueError):
         co.decode(bytes(bad), a.size, 2)
+
+
+def test_v2_fuzz_c_encoder_against_the_independent_python_decoder():
+    """120 random small chunks -- shapes with rows narrower and wider than a wave, planes smaller than
+    a row, both element kinds, flat / noisy / spiky / extreme data -- coded by the C restatement and
+    read back by tests/exac2_pyref.py (written from the format text alone), and by the C decoder."""
+    import exac2_pyref
+    rng = np.random.default_rng(20261006)
+    for it in range(120):
+        shape = tuple(int(v) for v in rng.integers(1, [7, 12, 90]))
+        kind = int(rng.integers(0, 5))
+        if rng.random() < 0.5:
+            base = rng.normal(rng.choice([0, 37, 3000, 60000]), rng.choice([0.0, 1.0, 4.0, 40.0, 900.0]), shape)
+            a = np.clip(base, 0, 65535).round().astype(np.uint16)
+            if kind == 0:
+                a.reshape(-1)[:: int(rng.integers(2, 9))] = rng.integers(0, 65536)
+        else:
+            a = rng.laplace(0, rng.choice([0.3, 2.0, 50.0, 1e5]), shape).round().astype(np.int64)
+            a = np.clip(a, -2 ** 31, 2 ** 31 - 1).astype(np.int32)
+            if kind == 1:
+                a.reshape(-1)[0] = -2 ** 31
+        b = co.encode(a)
+        got, shp = exac2_pyref.decode(b)
+        assert shp == co.shape3(shape), (it, shape)
+        np.testing.assert_array_equal(got, a.reshape(-1), err_msg=f"iteration {it}, shape {shape}")
+        back, used = co.decode(b, a.size, a.dtype.itemsize)
+        assert used == len(b)
+        np.testing.assert_array_equal(back, a.reshape(-1))
