@@ -219,3 +219,49 @@ def test_cpu_port_equals_the_oracle(oracle):
     b = oracle.bm4d_u16(u16, 24.0, 37.0, port=True)
     d = np.abs(a.astype(np.int32) - b.astype(np.int32))
     assert d.max() <= 1 and np.mean(d > 0) < 1e-3
+
+
+# ---- the C oracle against an independent numpy reading of DESIGN.md section 3 (tests/bm4d_pyref.py) ----------
+@pytest.mark.parametrize("shape,seed", [((12, 13, 16), 3), ((16, 16, 16), 4), ((9, 20, 24), 5), ((8, 8, 30), 6)])
+def test_oracle_agrees_with_an_independent_restatement_of_the_specification(oracle, shape, seed):
+    """BM4D is "parity unpinned" (the reference's bm4d wheel is absent); what CAN be pinned is that the
+    oracle says what the specification text says.  tests/bm4d_pyref.py was written from DESIGN.md 3.1-3.8
+    alone: grid, candidate set, fp32 fmaf-chain distances, packed keys and selection come out BIT-EXACT
+    (both stages, ragged extents with clamped last grid points); the collaborative filtering -- there
+    from the float64 definitions of DCT-II (x) Haar, hard threshold, Wiener weights, Kaiser window and
+    aggregation -- to 2e-5 on the denominators and 1e-3 counts on the estimates."""
+    import bm4d_pyref as R
+    vol, _ = synth_volume(shape, seed=seed)
+    keys = oracle.blockmatch(vol, SIGMA, 3.0)
+    np.testing.assert_array_equal(R.blockmatch(vol, SIGMA, 3.0), keys)
+    assert oracle.keymax(SIGMA, 3.0) == R.keymax(SIGMA, 3.0) and oracle.keymax(SIGMA, 0.6) == R.keymax(SIGMA, 0.6)
+    assert oracle.grid_positions(shape[1]).tolist() == R.grid(shape[1])
+    num_r, den_r = R.stage(vol, keys, SIGMA)
+    num_o, den_o = oracle.stage(vol, keys, SIGMA)
+    np.testing.assert_allclose(den_o, den_r, rtol=2e-5)
+    assert np.max(np.abs(num_o / den_o - num_r / den_r)) < 1e-3
+    basic = (num_o / den_o).astype(np.float32)
+    kw = oracle.blockmatch(basic, SIGMA, 0.6)
+    np.testing.assert_array_equal(R.blockmatch(basic, SIGMA, 0.6), kw)
+    num_r, den_r = R.stage(vol, kw, SIGMA, basic=basic)
+    num_o, den_o = oracle.stage(vol, kw, SIGMA, basic=basic)
+    np.testing.assert_allclose(den_o, den_r, rtol=5e-5)
+    assert np.max(np.abs(num_o / den_o - num_r / den_r)) < 1e-3
+
+
+def test_oracle_pipeline_against_the_independent_restatement(oracle):
+    """Whole two-stage pipeline, incl. integer-valued counts minus an offset (the uint16 form) and a
+    constant volume (every candidate ties at distance 0)."""
+    import bm4d_pyref as R
+    vol = (synth_volume((12, 16, 16), seed=9, as_u16=True)[0].astype(np.float32) - np.float32(37.0))
+    want = R.bm4d(vol, SIGMA)
+    got = oracle.bm4d(vol, SIGMA)
+    assert np.max(np.abs(got - want)) < 2e-2 and psnr(got, want, 1000.0) > 90.0
+    flat = np.full((9, 9, 12), 5.0, dtype=np.float32)
+    np.testing.assert_array_equal(R.blockmatch(flat, SIGMA, 3.0), oracle.blockmatch(flat, SIGMA, 3.0))
+    # the hard-threshold stage keeps a constant exactly; the Wiener stage scales its DC by
+    # W = Y^2 / (Y^2 + sigma^2) < 1 (3.7 filters the DC like any coefficient): both readings agree on that
+    assert np.max(np.abs(oracle.bm4d(flat, SIGMA, stages=1) - 5.0)) < 1e-4
+    assert np.max(np.abs(oracle.bm4d(flat, SIGMA) - R.bm4d(flat, SIGMA))) < 1e-4
+    dc2 = (5.0 * np.sqrt(512.0 * 16.0)) ** 2
+    assert abs(float(oracle.bm4d(flat, SIGMA)[4, 4, 6]) - 5.0 * dc2 / (dc2 + SIGMA ** 2)) < 1e-4
