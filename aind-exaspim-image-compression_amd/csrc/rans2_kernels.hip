@@ -153,44 +153,27 @@ __device__ __forceinline__ void renorm_put(uint32_t& x, uint32_t f, bool act, ui
 // bins).  (2) rans2_code_kernel: one wave per chunk turns the histograms into tables (lane = symbol),
 // writes header + tables into the chunk's slot and walks the codes from the last row to the first;
 // that loop is the serial rANS chain and touches nothing but the codes and an 8 KB table in LDS.
-// Codes are 16 bits per element: ctx | s << 4 (| low six raw bits << 10 for uint16 elements).  uint16
-// elements whose symbol carries more than six raw bits (s >= 37: |residual| >= 78) put the rest into a
-// second 16-bit array, written -- and later read -- only for the rows that have such an element (one
-// flag byte per row); int32 elements: the coder takes the raw bits from the element itself (zigzag of
-// the value, no taps needed).  (A first version used 32-bit codes: 4 B written + 4 B read per voxel.)
+// Codes: TS = 2: u32 = ctx | s << 4 | e << 10 (e < 2^15).  TS = 4: u16 = ctx | s << 4; the coder
+// takes the raw bits from the element itself (zigzag of the value, no taps needed).
 // Slot (scratch, per chunk): [0, 276) header, [276, 276 + 2048) table bytes, u32 table length at
 // SLOT2_TABLEN, 16-bit words from g.slot_hdr.
 constexpr int MODEL_WAVES = 4;            // waves per workgroup of the model kernel
 constexpr int MODEL_ROWS = 512;           // rows of 64 elements per workgroup (8 planes of a 64^3 chunk)
 
-struct CodeBufs {
-    uint16_t* code;          // [nchunks][chunk_elems]
-    uint16_t* ehi;           // uint16 elements: raw bits beyond the sixth, rows flagged in `flags` only
-    uint8_t* flags;          // [nchunks][rows_pad]: 1 iff the row has an element with more than six raw bits
-    uint32_t rows_pad;       // rows per chunk, padded to a multiple of 8
-};
-constexpr uint32_t LONG_RAW = 6;          // raw bits a 16-bit code carries itself
-
-// code (and, for a row with long raw values, the second array + the row's flag) of one row
 template <int TS>
-__device__ __forceinline__ void put_row(const CodeBufs& cb, size_t chunk_base, size_t flag_base, uint32_t r,
-                                        uint32_t lane, bool act, uint32_t ctx, uint32_t s, uint32_t nb, uint32_t e) {
-    const size_t at = chunk_base + (size_t)r * 64u + lane;
-    if (TS == 4) {
-        if (act) cb.code[at] = (uint16_t)(ctx | (s << 4));
-        return;
-    }
-    if (act) cb.code[at] = (uint16_t)(ctx | (s << 4) | ((e & 63u) << 10));
-    const bool longrow = __ballot(act && nb > LONG_RAW) != 0ull;
-    if (longrow && act) cb.ehi[at] = (uint16_t)(e >> LONG_RAW);
-    if (lane == 0) cb.flags[flag_base + r] = longrow ? 1 : 0;
+__device__ __forceinline__ void put_code(void* __restrict__ codes, size_t at, const Model& m) {
+    if (TS == 2)
+        static_cast<uint32_t*>(codes)[at] = m.ctx | (m.s << 4) | (m.e << 10);
+    else
+        static_cast<uint16_t*>(codes)[at] = (uint16_t)(m.ctx | (m.s << 4));
 }
 
 // Generic form: any chunk shape, every element models itself (three residuals for uint16; for int32
 // the residual is the zigzag value, so this is also the fast form of that kind).
 template <int TS>
 __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_kernel(const void* __restrict__ vol, CodecGeom g,
-                                                                        int blocks_per_chunk, CodeBufs cb,
+                                                                        int blocks_per_chunk,
+                                                                        void* __restrict__ codes,
                                                                         uint32_t* __restrict__ ghist) {
     constexpr int NC = EXABM4D_ENC2_NC, RB = EXABM4D_ENC2_RB;
     __shared__ uint32_t hist[NCTX * NSYM * NC];
@@ -237,12 +220,11 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_kernel(const voi
                 m[k] = model_of<TS>(vol, b.base, t, i, p, act[k]);
             }
 #pragma unroll
-            for (int k = 0; k < RB; k++) {
-                if (r0 + k >= r_hi) break;                                   // wave-uniform
-                if (act[k]) atomicAdd(&hist[(m[k].ctx * NSYM + m[k].s) * NC + (lane & (NC - 1))], 1u);
-                put_row<TS>(cb, cbase, (size_t)c * cb.rows_pad, r0 + k, lane, act[k], m[k].ctx, m[k].s, m[k].nb,
-                            m[k].e);
-            }
+            for (int k = 0; k < RB; k++)
+                if (act[k]) {
+                    atomicAdd(&hist[(m[k].ctx * NSYM + m[k].s) * NC + (lane & (NC - 1))], 1u);
+                    put_code<TS>(codes, cbase + (size_t)(r0 + k) * 64u + lane, m[k]);
+                }
         }
     }
     __syncthreads();
@@ -264,7 +246,8 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_kernel(const voi
 constexpr int STRIP = 16;
 __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_strips_kernel(const uint16_t* __restrict__ vol,
                                                                                CodecGeom g, int blocks_per_chunk,
-                                                                               int planes_per_block, CodeBufs cb,
+                                                                               int planes_per_block,
+                                                                               uint32_t* __restrict__ codes,
                                                                                uint32_t* __restrict__ ghist) {
     constexpr int NC = EXABM4D_ENC2_NC;
     __shared__ uint32_t hist[NCTX * NSYM * NC];
@@ -281,7 +264,7 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_strips_kernel(co
     if (z_lo < z_hi && q0 < ey) {
         const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * g.ny;
         const uint16_t* v16 = vol + b.base + lane;
-        const size_t cbase = (size_t)c * g.chunk_elems, fbase = (size_t)c * cb.rows_pad;
+        uint32_t* crow = codes + (size_t)c * g.chunk_elems + lane;
         auto zig = [](uint32_t v, uint32_t pred) -> uint32_t {
             const int32_t r = (int32_t)(int16_t)(uint16_t)(v - pred);
             return (uint32_t)(((r << 1) ^ (r >> 15)) & 0xFFFF);
@@ -344,7 +327,7 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_strips_kernel(co
                 uint32_t sy_, nb_, e_;
                 symbol_of(u, sy_, nb_, e_);
                 atomicAdd(&hist[(ctx * NSYM + sy_) * NC + (lane & (NC - 1))], 1u);
-                put_row<2>(cb, cbase, fbase, z * ey + q, lane, true, ctx, sy_, nb_, e_);
+                crow[((size_t)z * ey + q) * 64u] = ctx | (sy_ << 4) | (e_ << 10);
             }
 #pragma unroll
             for (int k = 0; k < STRIP; k++) {
@@ -369,7 +352,7 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_strips_kernel(co
 // the DCT-index leg (chunks of 512 blocks x 8 x 64 coefficients).
 __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_rows32_kernel(const int32_t* __restrict__ vol,
                                                                                CodecGeom g, int blocks_per_chunk,
-                                                                               CodeBufs cb,
+                                                                               uint16_t* __restrict__ codes,
                                                                                uint32_t* __restrict__ ghist) {
     constexpr int NC = EXABM4D_ENC2_NC, RB = 8;
     __shared__ uint32_t hist[NCTX * NSYM * NC];
@@ -387,7 +370,7 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_rows32_kernel(co
         const bool use_u = ex <= TAP_LIMIT, use_b = (uint64_t)ex * ey <= TAP_LIMIT;
         const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * g.ny;
         const int32_t* v32 = vol + b.base + lane;
-        uint16_t* crow = cb.code + (size_t)c * g.chunk_elems + lane;
+        uint16_t* crow = codes + (size_t)c * g.chunk_elems + lane;
         auto zz = [](int32_t v) -> uint32_t { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); };
         RowCursor rc;
         rc.rpx = rpx;
@@ -432,7 +415,8 @@ __global__ __launch_bounds__(64 * MODEL_WAVES) void rans2_model_rows32_kernel(co
 
 template <int TS>
 __global__ __launch_bounds__(64) void rans2_code_kernel(const void* __restrict__ vol, CodecGeom g,
-                                                        const uint2* __restrict__ rcp_tab, CodeBufs cb,
+                                                        const uint2* __restrict__ rcp_tab,
+                                                        const void* __restrict__ codes,
                                                         const uint32_t* __restrict__ ghist,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ sizes) {
     constexpr int RB = 8;
@@ -515,17 +499,14 @@ __global__ __launch_bounds__(64) void rans2_code_kernel(const void* __restrict__
         rc.ey = (uint32_t)b.ey;
         rc.xr = rc.y = rc.z = 0;
         const size_t cbase = (size_t)c * g.chunk_elems;
-        const uint16_t* c16 = cb.code + cbase;
-        const uint16_t* h16 = cb.ehi + (TS == 2 ? cbase : 0);
-        const uint8_t* rowflag = cb.flags + (size_t)c * cb.rows_pad;
+        const uint32_t* c32 = static_cast<const uint32_t*>(codes) + (TS == 2 ? cbase : 0);
+        const uint16_t* c16 = static_cast<const uint16_t*>(codes) + (TS == 4 ? cbase : 0);
 
-        // code word and raw value of element i of row r; `longrow`: the row has raw values beyond
-        // the six bits a code carries (wave-uniform)
-        auto fetch = [&](uint32_t r, uint32_t i, bool act, bool longrow, uint32_t& code, uint32_t& ev) {
+        // code word and raw value of element i of row r
+        auto fetch = [&](uint32_t r, uint32_t i, bool act, uint32_t& code, uint32_t& ev) {
             if (TS == 2) {
-                code = act ? c16[i] : 0u;
+                code = act ? c32[i] : 0u;
                 ev = code >> 10;
-                if (longrow && act) ev |= (uint32_t)h16[i] << LONG_RAW;
             } else {
                 int32_t v = 0;
                 code = 0u;
@@ -578,20 +559,17 @@ __global__ __launch_bounds__(64) void rans2_code_kernel(const void* __restrict__
             const uint32_t i = (r - 1u) * 64u + lane;
             const bool act = i < n;
             uint32_t code, ev;
-            fetch(r - 1u, i, act, TS == 2 && rowflag[r - 1u] != 0, code, ev);
+            fetch(r - 1u, i, act, code, ev);
             if (TS == 4 && fast) rc.prev();
             code_row(code, ev, etab[code & 0x3FFu], act);
         }
         for (uint32_t rb = batched; rb > 0; rb -= RB) {
             uint32_t code[RB], ev[RB];
             uint2 e[RB];
-            // the batch's eight row flags are one aligned 8-byte word (rb is a multiple of RB = 8)
-            static_assert(RB == 8, "one flag word per batch");
-            const unsigned long long f8 = TS == 2 ? *reinterpret_cast<const unsigned long long*>(rowflag + rb - RB) : 0ull;
 #pragma unroll
             for (int k = 0; k < RB; k++) {
                 const uint32_t r = rb - 1 - k;
-                fetch(r, r * 64u + lane, true, ((f8 >> (8 * (RB - 1 - k))) & 0xFFull) != 0ull, code[k], ev[k]);
+                fetch(r, r * 64u + lane, true, code[k], ev[k]);
                 if (TS == 4 && fast) rc.prev();
             }
 #pragma unroll
@@ -860,16 +838,9 @@ void codec2_slot_layout(size_t chunk_elems, int ts, size_t& slot_hdr, size_t& sl
     slot_bytes = slot_hdr + ((2 * ((size_t)(ts == 2 ? 3 : 4) * chunk_elems + 128) + 15) & ~(size_t)15);
 }
 
-static size_t rows_padded(const CodecGeom& g) {
-    return ((g.chunk_elems + 63) / 64 + 7) & ~(size_t)7;
-}
-static size_t align256(size_t v) {
-    return (v + 255) & ~(size_t)255;
-}
 size_t codec2_work_bytes(const CodecGeom& g) {
-    // 16-bit codes of every element, (uint16) the second array, row flags, the 16 x 64 histograms
-    const size_t cbytes = align256((size_t)g.nchunks * g.chunk_elems * 2);
-    return cbytes * (g.ts == 2 ? 2 : 1) + align256((size_t)g.nchunks * rows_padded(g)) +
+    // packed codes of every element (u32 / u16) + the 16 x 64 histogram of every chunk
+    return (((size_t)g.nchunks * g.chunk_elems * (g.ts == 2 ? 4 : 2) + 255) & ~(size_t)255) +
            (size_t)g.nchunks * NCTX * NSYM * sizeof(uint32_t);
 }
 
@@ -882,13 +853,9 @@ hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32
                            out);
         return hipGetLastError();
     }
-    const size_t cbytes = align256((size_t)g.nchunks * g.chunk_elems * 2);
-    CodeBufs codes;
-    codes.code = reinterpret_cast<uint16_t*>(work);
-    codes.ehi = reinterpret_cast<uint16_t*>(work + (g.ts == 2 ? cbytes : 0));
-    codes.flags = work + cbytes * (g.ts == 2 ? 2 : 1);
-    codes.rows_pad = (uint32_t)rows_padded(g);
-    uint32_t* ghist = reinterpret_cast<uint32_t*>(codes.flags + align256((size_t)g.nchunks * rows_padded(g)));
+    void* codes = work;
+    const size_t cbytes = ((size_t)g.nchunks * g.chunk_elems * (g.ts == 2 ? 4 : 2) + 255) & ~(size_t)255;
+    uint32_t* ghist = reinterpret_cast<uint32_t*>(work + cbytes);
     hipError_t e = hipMemsetAsync(ghist, 0, (size_t)g.nchunks * NCTX * NSYM * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     // every chunk of the volume has ex = min(cx, rest of the row): the strips form needs 64 everywhere
@@ -897,12 +864,12 @@ hipError_t launch_rans2_encode(const void* vol, const CodecGeom& g, const uint32
         const int ppb = 16;                                                // planes per workgroup
         const int bpc = (g.cz + ppb - 1) / ppb;
         hipLaunchKernelGGL(rans2_model_strips_kernel, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
-                           static_cast<const uint16_t*>(vol), g, bpc, ppb, codes, ghist);
+                           static_cast<const uint16_t*>(vol), g, bpc, ppb, static_cast<uint32_t*>(codes), ghist);
     } else if (g.ts == 4 && (g.cx % 64) == 0 && (g.nx % g.cx) == 0) {
         const size_t rows = g.chunk_elems / 64;
         const int bpc = (int)((rows + MODEL_ROWS - 1) / MODEL_ROWS);
         hipLaunchKernelGGL(rans2_model_rows32_kernel, dim3((unsigned)g.nchunks * bpc), dim3(64 * MODEL_WAVES), 0, s,
-                           static_cast<const int32_t*>(vol), g, bpc, codes, ghist);
+                           static_cast<const int32_t*>(vol), g, bpc, static_cast<uint16_t*>(codes), ghist);
     } else {
         const size_t rows = (g.chunk_elems + 63) / 64;
         const int bpc = (int)((rows + MODEL_ROWS - 1) / MODEL_ROWS);
