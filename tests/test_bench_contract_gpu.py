@@ -107,3 +107,25 @@ def test_launcher_parent_never_touches_the_gpu_or_torch():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
                          env=env)
     assert out.returncode == 0 and "parent clean" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["volumes", "slabs", "chunks"])
+def test_two_real_gpus_over_rccl(mode):
+    """Where the box has at least two GPUs: the same launcher WITHOUT the rehearsal switch -- one rank
+    per GPU, `nccl` (= RCCL) rendezvous, the halo exchanges of the slab / chunk modes over xGMI
+    (HaloExchange: int16 planes as bytes, batch_isend_irecv).  Skipped on the one-GPU boxes the builder
+    and the driver's test tier get; the driver's scaling run is the first place it executes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "BENCH_REHEARSAL"):
+        env.pop(k, None)
+    extra = ["--mode", mode] + (["--chunk", "64"] if mode == "chunks" else [])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "128",
+                          "--steps", "1", "--warmup", "1", "--bm4dnet", "0", "--cpu-sample", "0", *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["n_gpus"] == 2 and 15.0 < d["residual_std"] < 30.0        # a denoised volume came back on rank 0
