@@ -333,6 +333,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->bm_int = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "stage_pairvol") == 0) {      // Wiener gathers from an interleaved (noisy, basic) volume
+        g_stage_pairvol = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "stage_quads") == 0) {        // Wiener stage: four (1) or two (0) waves per group
         g_stage_quads = value ? 1 : 0;
         return EXABM4D_OK;
@@ -435,7 +439,9 @@ size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages) {
     // keys, num, den, [basic], and the two work volumes of the denominator convolution
     size_t b = align256(nref * MAXG * sizeof(uint32_t)) + 2 * align256(n * sizeof(float));
     if (stages >= 2) b += align256(n * sizeof(float));
-    b += align256(2 * n * sizeof(float));
+    // corner weights + ping-pong of the denominator convolution; with a Wiener stage also the
+    // interleaved (noisy, basic) volume its gathers read
+    b += align256((stages >= 2 ? 4 : 2) * n * sizeof(float));
     return b;
 }
 
@@ -542,11 +548,12 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
     const size_t n = (size_t)g.nvox * (size_t)batch;
-    rc = ensure_scratch(ctx, align256(2 * n * sizeof(float)));
+    rc = ensure_scratch(ctx, align256((basic ? 4 : 2) * n * sizeof(float)));
     if (rc) return rc;
     HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, num,
                               den, ctx->stream, ctx->stage_pairs, ctx->win1d,
-                              static_cast<float*>(ctx->scratch), 0));
+                              static_cast<float*>(ctx->scratch), 0,
+                              basic ? static_cast<float*>(ctx->scratch) + 2 * n : nullptr));
     return EXABM4D_OK;
 }
 
@@ -675,7 +682,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
             HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode));
+                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode,
+                                      cwork + 2 * n));
         }
     }
     {

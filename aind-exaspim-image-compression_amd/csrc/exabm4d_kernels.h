@@ -64,7 +64,10 @@ extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chun
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite);
+                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite,
+                        float* pair = nullptr);     // pair: 2 n floats of scratch for the Wiener stage's
+                                                    // interleaved (noisy, basic) volume, or NULL
+extern int g_stage_pairvol;
 // den += C (*) win for the separable window win = k (x) k (x) k: fused x / y pass C -> tmp, z pass
 // den += conv(tmp) (den = conv(tmp) with `overwrite`: the caller need not zero den first).
 hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,

@@ -145,6 +145,20 @@ __device__ __forceinline__ void haar_inv2(f2 (&v)[MAXG]) {
     }
 }
 
+// Wiener stage: both volumes of a block with ONE load per row from the interleaved (noisy, basic)
+// float2 volume -- half the cache lines of two separate gathers (the Wiener kernel spends half of
+// its time stalled on L1 misses of its gathers).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gather8v2(__amdgpu_buffer_rsrc_t rsrc, int corner2, const unsigned (&voff)[8],
+                                          float (&a)[8], float (&b)[8]) {
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        const u2v t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(2u * voff[y]), corner2, 0);
+        a[y] = __uint_as_float(t.x);
+        b[y] = __uint_as_float(t.y);
+    }
+}
+
 // Hard threshold.  Spectrum layout: S[jp][2k + c] = coefficient plane j = 2 jp + c of block k,
 // so that the Haar transforms of two coefficient planes run as one packed instruction stream.
 template <int K>
@@ -856,7 +870,8 @@ __device__ __forceinline__ bool process_half_group(
     const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, ring_t* ring,
     float* __restrict__ cvol, f2* tb,
     f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int& seen, int layer, int target,
-    int lane, long long g_nvox, float* __restrict__ num, const VolGeom& g, int izb
+    int lane, long long g_nvox, float* __restrict__ num, const VolGeom& g, int izb,
+    const f2* __restrict__ pair
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
 #endif
@@ -911,6 +926,10 @@ __device__ __forceinline__ bool process_half_group(
             const_cast<float*>((WIENER ? basic : noisy) + win_off), 0, win_bytes, 0x00020000);
         const int my_rel = lane < MAXG ? (int)(4u * (unsigned)(my_corner - win_off)) : 0;
         auto corner_of = [&](int k) -> int { return __builtin_amdgcn_readlane(my_rel, k); };
+        // Wiener with the interleaved volume: 8-byte elements, the same window
+        const __amdgpu_buffer_rsrc_t pair_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<f2*>((WIENER && pair ? pair : reinterpret_cast<const f2*>(noisy)) + (WIENER && pair ? win_off : 0)), 0,
+            (int)min(win_left * sizeof(f2), (size_t)0x7FFFFFFFu * 2u), 0x00020000);
         // Forward transforms of my blocks, two streams per transform: blocks (kl, kl + 1) of one
         // volume (a half of one block pairs the noisy block with the basic one in the Wiener
         // stage, and runs the block twice in the hard-threshold stage).  The next gather is
@@ -971,8 +990,12 @@ __device__ __forceinline__ bool process_half_group(
             }
         } else if constexpr (KH == 1) {
             const size_t c0 = corner_of(kb);
-            gather8v(noisy_r, c0, voff, a);
-            gather8v(basic_r, c0, voff, b);
+            if (pair) {
+                gather8v2(pair_r, 2 * (int)c0, voff, a, b);
+            } else {
+                gather8v(noisy_r, c0, voff, a);
+                gather8v(basic_r, c0, voff, b);
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
             pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
@@ -980,6 +1003,22 @@ __device__ __forceinline__ bool process_half_group(
             for (int j = 0; j < 8; j++) {
                 S[j >> 1][j & 1] = v2[j].x;
                 SB[j >> 1][j & 1] = v2[j].y;
+            }
+        } else if (pair) {
+            // interleaved volume: block k's noisy and basic values arrive together and are the two
+            // packed streams of its transform (same arithmetic per stream as the other pairing)
+            gather8v2(pair_r, 2 * corner_of(kb), voff, a, b);
+#pragma unroll
+            for (int kl = 0; kl < KH; kl++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
+                if (kl + 1 < KH) gather8v2(pair_r, 2 * corner_of(kb + kl + 1), voff, a, b);
+                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
+                    SB[j >> 1][2 * kl + (j & 1)] = v2[j].y;
+                }
             }
         } else {
             gather8v(noisy_r, corner_of(kb), voff, a);
@@ -1249,7 +1288,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
     const uint32_t* __restrict__ keys_all, VolGeom g, HalfTable T, const float* __restrict__ win_g,
     float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x,
-    int layers_per_chunk) {
+    int layers_per_chunk, const f2* __restrict__ pair_all) {
     using C = HalfCfg<WIENER>;
     constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, HTY = C::TY, HTX = C::TX;
     extern __shared__ __align__(16) float lds[];
@@ -1265,6 +1304,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
     const float* __restrict__ noisy = noisy_all + voff;
     const float* __restrict__ basic = WIENER ? basic_all + voff : nullptr;
+    const f2* __restrict__ pair = (WIENER && pair_all) ? pair_all + voff : nullptr;
     float* __restrict__ num = num_all + voff;
     float* __restrict__ cvol = cvol_all + voff;
     const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
@@ -1334,7 +1374,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
 #endif
             const bool closer = process_half_group<WIENER>(
                 noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, ring, cvol, tb,
-                partner_tb, lock, sync, cnt, wave, seq, seen, layer, 2 * nrefs, lane, g.nvox, num, g, izb
+                partner_tb, lock, sync, cnt, wave, seq, seen, layer, 2 * nrefs, lane, g.nvox, num, g, izb, pair
 #ifdef EXABM4D_STAMPS
                 , st
 #endif
@@ -1848,6 +1888,24 @@ __global__ __launch_bounds__(QuadCfg::NW * 64) void stage_quad_kernel(
     }
 }
 
+// (noisy, basic) -> float2 volume for the Wiener kernel's gathers
+__global__ __launch_bounds__(256) void interleave_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              f2* __restrict__ out, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const f4 x = *reinterpret_cast<const f4*>(a + i), y = *reinterpret_cast<const f4*>(b + i);
+            f4 lo, hi;
+            lo.x = x.x; lo.y = y.x; lo.z = x.y; lo.w = y.y;
+            hi.x = x.z; hi.y = y.z; hi.z = x.w; hi.w = y.w;
+            *reinterpret_cast<f4*>(out + i) = lo;
+            *reinterpret_cast<f4*>(out + i + 2) = hi;
+        } else {
+            for (size_t j = i; j < n; j++) out[j] = mk2(a[j], b[j]);
+        }
+    }
+}
+int g_stage_pairvol = 1;     // exabm4d_set_option("stage_pairvol"): Wiener gathers from an interleaved (noisy, basic) volume
+
 int g_stage_quads = EXABM4D_WIE_QUADS;   // exabm4d_set_option("stage_quads"): Wiener stage on teams of four waves
 
 constexpr int NW_HT = 4;
@@ -1857,7 +1915,7 @@ int g_stage_chunks = 0;      // exabm4d_set_option("stage_chunks"): z chunks of 
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite) {
+                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite, float* pair) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
     const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
@@ -1900,8 +1958,14 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<W>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (err != hipSuccess) return err;
+            const f2* pairvol = nullptr;
+            if (W && pair && g_stage_pairvol && (n % 4) == 0) {
+                f2* pv = reinterpret_cast<f2*>(pair);
+                hipLaunchKernelGGL(interleave_pair_kernel, dim3(65536), dim3(256), 0, stream, noisy, basic, pv, n);
+                pairvol = pv;
+            }
             hipLaunchKernelGGL(stage_half_kernel<W>, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys,
-                               g, HT, win_dev, thr, sigma2, num, cwork, htx, hlpc);
+                               g, HT, win_dev, thr, sigma2, num, cwork, htx, hlpc, pairvol);
             return hipGetLastError();
         };
         auto launch_quads = [&]() -> hipError_t {
