@@ -485,3 +485,33 @@ def test_fused_denominator_z_pass_is_bit_identical(ctx, shape):
         d = np.abs(a.astype(np.float64) - b.astype(np.float64))
         assert d.max() <= (1 if a.dtype == np.uint16 else 0.05), float(d.max())
         assert np.mean(d > 0) < (2e-3 if a.dtype == np.uint16 else 1.0)
+
+
+def test_wiener_gathers_from_the_interleaved_volume(ctx, oracle):
+    """Round 3: the Wiener kernel reads block k's noisy and basic values with one 8-byte load per row
+    from an interleaved (noisy, basic) volume (half the cache lines of two gathers) and runs them as
+    the two packed streams of one transform -- per stream the same IEEE operations as before, so the
+    spectra are bit-identical and the stage output differs only by the aggregation's arrival order.
+    Against the separate gathers (option stage_pairvol = 0) on a volume with every group size, and
+    against the oracle on a crop."""
+    shape = (40, 200, 208)
+    noisy = _mixed_volume(shape, 41)
+    basic = (noisy + np.random.default_rng(6).normal(0, 2.0, shape)).astype(np.float32)
+    keys = _keys_gpu(ctx, basic, SIGMA, 3.0)
+    assert np.unique((keys != 0xFFFFFFFF).sum(axis=-1)).size > 4
+    res = {}
+    try:
+        for pv in (1, 0):
+            ctx.set_option("stage_pairvol", pv)
+            res[pv] = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic)
+    finally:
+        ctx.set_option("stage_pairvol", 1)
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=2e-5)
+    _assert_close_estimates(res[1][0] / res[1][1], res[0][0] / res[0][1], SIGMA)
+    sub = (slice(0, 32), slice(60, 108), slice(40, 88))
+    cn, cb = np.ascontiguousarray(noisy[sub]), np.ascontiguousarray(basic[sub])
+    kc = oracle.blockmatch(cb, SIGMA, 3.0)
+    num_w, den_w = oracle.stage(cn, kc, SIGMA, basic=cb)
+    num_g, den_g = _stage_gpu(ctx, cn, kc, SIGMA, basic=cb)
+    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
+    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
