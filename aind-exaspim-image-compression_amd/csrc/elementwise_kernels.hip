@@ -514,7 +514,11 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float
                                                                      const float* __restrict__ txy,
                                                                      void* __restrict__ out, size_t nlines,
                                                                      size_t plane, int nz, Win1D w, float lo,
-                                                                     float hi, int do_clip, float offset) {
+                                                                     float hi, int do_clip, float offset,
+                                                                     const float* __restrict__ pair_src,
+                                                                     float* __restrict__ pair_out) {
+    // pair_out (fp32 output, W = 4 only): additionally the interleaved volume (pair_src, out) the Wiener
+    // kernel gathers from, so that it does not cost a pass of its own
     const size_t lines_per_vol = plane / W;
     for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
          l += (size_t)gridDim.x * EW_THREADS) {
@@ -563,10 +567,17 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float
 #pragma unroll
                 for (int j = 0; j < W; j++)
                     if (do_clip) r[j] = fminf(fmaxf(r[j], lo), hi);
-                if (W == 4)
+                if (W == 4) {
                     *reinterpret_cast<float4*>(o32) = make_float4(r[0], r[1 % W], r[2 % W], r[3 % W]);
-                else
+                    if (pair_out) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(pair_src + at);
+                        float4* po = reinterpret_cast<float4*>(pair_out + 2 * at);
+                        po[0] = make_float4(s4.x, r[0], s4.y, r[1 % W]);
+                        po[1] = make_float4(s4.z, r[2 % W], s4.w, r[3 % W]);
+                    }
+                } else {
                     o32[0] = r[0];
+                }
             }
         }
     }
@@ -596,7 +607,8 @@ hipError_t launch_den_xy_from_corners(float* C, float* tmp, int nz, int ny, int 
 // out = num / (txy (*)_z win): exactly one of out_f32 / out_u16
 hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out_f32, uint16_t* out_u16, int nz,
                                   int ny, int nx, int batch, const float* win1d, float lo, float hi, float offset,
-                                  hipStream_t s) {
+                                  hipStream_t s, const float* pair_src, float* pair_out, int* pair_written) {
+    if (pair_written) *pair_written = 0;
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
     const size_t plane = (size_t)ny * nx;
@@ -608,18 +620,23 @@ hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out
     if (b > 65536) b = 65536;
     const dim3 grid((unsigned)(b ? b : 1));
     const int clip = lo <= hi ? 1 : 0;
-    if (wide && out_u16)
+    const float* nul = nullptr;
+    float* nulw = nullptr;
+    if (wide && out_u16) {
         hipLaunchKernelGGL((normalize_zconv_kernel<4, true>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines, plane,
-                           nz, w, lo, hi, clip, offset);
-    else if (wide)
+                           nz, w, lo, hi, clip, offset, nul, nulw);
+    } else if (wide) {
+        const bool pw = pair_src && pair_out && ((uintptr_t)pair_src & 15u) == 0 && ((uintptr_t)pair_out & 15u) == 0;
         hipLaunchKernelGGL((normalize_zconv_kernel<4, false>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines,
-                           plane, nz, w, lo, hi, clip, offset);
-    else if (out_u16)
+                           plane, nz, w, lo, hi, clip, offset, pw ? pair_src : nul, pw ? pair_out : nulw);
+        if (pair_written && pw) *pair_written = 1;
+    } else if (out_u16) {
         hipLaunchKernelGGL((normalize_zconv_kernel<1, true>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines, plane,
-                           nz, w, lo, hi, clip, offset);
-    else
+                           nz, w, lo, hi, clip, offset, nul, nulw);
+    } else {
         hipLaunchKernelGGL((normalize_zconv_kernel<1, false>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines,
-                           plane, nz, w, lo, hi, clip, offset);
+                           plane, nz, w, lo, hi, clip, offset, nul, nulw);
+    }
     return hipGetLastError();
 }
 

@@ -633,6 +633,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     // (cwork + n holds the x / y passes' result), unless the option asks for the separate pass
     const bool fused = ctx->stage_pairs && ctx->fuse_den_z;
     const int den_mode = fused ? 2 : ctx->stage_pairs;
+    int pair_ready = 0;      // the first normalisation wrote the Wiener stage's (noisy, basic) volume
     if (ctx->profile)
         for (int i = 1; i < EXABM4D_PHASE_COUNT; i++) ctx->ev_used[i] = false;
     if ((noisy_guarded && !guarded_region_ok(ctx, noisy, n * sizeof(float))) ||
@@ -663,9 +664,10 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     if (stages >= 2) {
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_BASIC);
-            if (fused)
+            if (fused)        // ... and, where it can, the Wiener stage's interleaved (noisy, basic) volume
                 HIP_TRY(ctx, launch_normalize_zconv(num, cwork + n, basic, nullptr, g.nz, g.ny, g.nx, batch,
-                                                    ctx->win1d, 1.0f, 0.0f, 0.0f, s));
+                                                    ctx->win1d, 1.0f, 0.0f, 0.0f, s,
+                                                    g_stage_pairvol ? noisy : nullptr, cwork + 2 * n, &pair_ready));
             else
                 HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
         }
@@ -683,7 +685,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
             HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
                                       sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode,
-                                      cwork + 2 * n));
+                                      cwork + 2 * n, pair_ready));
         }
     }
     {

@@ -65,7 +65,7 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
                         int wave_pairs, const float* win1d, float* cwork, int den_overwrite,
-                        float* pair = nullptr);     // pair: 2 n floats of scratch for the Wiener stage's
+                        float* pair = nullptr, int pair_ready = 0);   // pair_ready: the caller has filled it     // pair: 2 n floats of scratch for the Wiener stage's
                                                     // interleaved (noisy, basic) volume, or NULL
 extern int g_stage_pairvol;
 // den += C (*) win for the separable window win = k (x) k (x) k: fused x / y pass C -> tmp, z pass
@@ -77,9 +77,12 @@ hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int
 // out = num / (tmp (*)_z win), then clip (f32) or + offset, clamp, rint (uint16).
 hipError_t launch_den_xy_from_corners(float* C, float* tmp, int nz, int ny, int nx, int batch, const float* win1d,
                                       hipStream_t s);
+// pair_src / pair_out (optional, fp32 output only): also write the interleaved (pair_src, out) volume of the
+// Wiener stage's gathers; *pair_written says whether this launch could do it (16-byte aligned float4 form)
 hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out_f32, uint16_t* out_u16, int nz,
                                   int ny, int nx, int batch, const float* win1d, float lo, float hi, float offset,
-                                  hipStream_t s);
+                                  hipStream_t s, const float* pair_src = nullptr, float* pair_out = nullptr,
+                                  int* pair_written = nullptr);
 
 // ---- chunk-local mode (elementwise_kernels.hip) ------------------------------------------------------
 // One batch of equally shaped padded chunks out of a sub-grid of chunks (sgz x sgy x sgx chunks

@@ -1915,7 +1915,8 @@ int g_stage_chunks = 0;      // exabm4d_set_option("stage_chunks"): z chunks of 
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
                         float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite, float* pair) {
+                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite, float* pair,
+                        int pair_ready) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
     const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
@@ -1959,9 +1960,10 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (err != hipSuccess) return err;
             const f2* pairvol = nullptr;
-            if (W && pair && g_stage_pairvol && (n % 4) == 0) {
+            if (W && pair && g_stage_pairvol && (pair_ready || (n % 4) == 0)) {
                 f2* pv = reinterpret_cast<f2*>(pair);
-                hipLaunchKernelGGL(interleave_pair_kernel, dim3(65536), dim3(256), 0, stream, noisy, basic, pv, n);
+                if (!pair_ready)
+                    hipLaunchKernelGGL(interleave_pair_kernel, dim3(65536), dim3(256), 0, stream, noisy, basic, pv, n);
                 pairvol = pv;
             }
             hipLaunchKernelGGL(stage_half_kernel<W>, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys,
