@@ -90,8 +90,10 @@ def main():
         # one count where the two fp32 summation orders round apart, or where the last bits of the
         # basic estimate moved a stage-2 match table (tests/test_pipeline_differences_gpu.py pins
         # both mechanisms; volumes with isolated 0 / 65535 voxels reach 0.5 % by the second one,
-        # whatever the offset -- tools/dbg/tie_probe.py)
-        ok_pipe = d.max() <= 1 and np.mean(d > 0) < 2e-2
+        # whatever the offset -- tools/dbg/tie_probe.py).  A changed group can move a voxel by more
+        # than a count (seen: 2 at sigma 110 on an "extremes" volume, 3 in bench.py's psnr block);
+        # the aggregation order varies between launches, so the same input does not always show it
+        ok_pipe = d.max() <= 3 and np.mean(d > 1) < 1e-4 and np.mean(d > 0) < 2e-2
         del f
 
         # chunk coder on the denoised volume, random chunk grid
@@ -109,7 +111,7 @@ def main():
             b.free()
         print(f"{it:4d} {name:9s} {str(shape):14s} sigma {sigma:5.1f} offset {offset:5.1f} chunk {chunk} "
               f"keys {'ok' if ok_keys else 'MISMATCH'} pipeline max|d| {int(d.max())} "
-              f"frac {float(np.mean(d > 0)):.1e} {'ok' if ok_pipe else 'MISMATCH'} "
+              f"frac {float(np.mean(d > 0)):.1e} beyond one {float(np.mean(d > 1)):.1e} {'ok' if ok_pipe else 'MISMATCH'} "
               f"codec {'ok' if ok_codec else 'MISMATCH'}", flush=True)
         if not (ok_keys and ok_pipe and ok_codec):
             np.save(os.path.join(ROOT, "gpurun_out", "fuzz_fail_vol.npy"), vol)
