@@ -115,7 +115,17 @@ int exabm4d_default_params(exabm4d_params* p);
  * two-waves-per-group ones (same arithmetic; kept as a cross-check).
  * "bm_guarded_copy" = 1 makes exabm4d_blockmatch_dev match on a copy of the volume inside the
  * library's scratch allocation, the way the exabm4d_denoise_* pipelines do (x-edge tiles then
- * stream their planes by LDS-DMA without clamping); for the parity tests. */
+ * stream their planes by LDS-DMA without clamping); for the parity tests.
+ * Round 3: "codec_version" = 1 | 2 (default 2): the EXAC format exabm4d_codec_encode_dev writes (the
+ * option is per context, not per call: do not switch it from two threads of one context);
+ * "fuse_den_z" = 0 runs the denominator's z pass and the normalisation as separate kernels (default 1:
+ * fused, bit-identical); "stage_pairvol" = 0 makes the Wiener kernel gather its two
+ * volumes separately (default 1: one interleaved volume); "stage_quads" = 1 runs the
+ * Wiener stage on teams of four waves per group (default 0: measured slower);
+ * "bm_int" = 0 keeps the uint16 pipelines' stage-1 matching on the float kernel; "stage_chunks",
+ * "chunk_budget_mb", "profile": z chunks of the stage kernels (0 = automatic), scratch budget of the
+ * chunk-local mode, per-phase HIP events for exabm4d_profile_read.  "stage_pairvol", "stage_quads" and
+ * "stage_chunks" are process-wide. */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
 /* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
  * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and
