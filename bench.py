@@ -423,7 +423,7 @@ def run_slabs(args, rank, local_rank, world, dist):
     if rank == 0:
         resid = (out[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float() - \
                 (raw[plan.core][::8, ::8, ::8].to(torch.int32) & 0xFFFF).float()
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "denoised+encoded voxels/s on 1024^3 uint16",
             "value": world * n ** 3 * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -438,7 +438,7 @@ def run_slabs(args, rank, local_rank, world, dist):
             "residual_std": float(resid.std()),
             "rank0_lossless_cratio": None if args.no_encode else
             round(2.0 * float(np.prod(own)) / float(sz16.sum().item()), 2),
-        }), flush=True)
+        }))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -492,7 +492,7 @@ def run_chunks(args, rank, local_rank, world, dist):
     if rank == 0:
         resid = (out[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float() - \
                 (own[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float()
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "denoised+encoded voxels/s on 1024^3 uint16",
             "value": world * n ** 3 * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -508,10 +508,31 @@ def run_chunks(args, rank, local_rank, world, dist):
             "residual_std": float(resid.std()),
             "rank0_lossless_cratio": None if args.no_encode else
             round(2.0 * float(np.prod(own_shape)) / float(sz16.sum().item()), 2),
-        }), flush=True)
+        }))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_RESULT_FD = None
+
+
+def quiet_stdout():
+    """Multi-rank runs: collective back-ends may print to stdout (gloo announces its peers there), and
+    the driver parses stdout as ONE JSON line.  Everything written to fd 1 from here on goes to stderr;
+    the result line goes to the original stdout through emit()."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_RESULT_FD, (line + "\n").encode())
 
 
 def launch_ranks(n):
@@ -598,6 +619,7 @@ def main():
     # rendezvous, every rank on device 0 (never the measured configuration).
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if world > 1:
+        quiet_stdout()
         import torch
         import torch.distributed as dist
         if rehearsal:
@@ -822,7 +844,7 @@ def main():
                 result["bm4dnet"] = bm4dnet_leg(vol, tune_edge=args.bm4dnet_tune)
             except Exception as e:                    # the metric line must not die with the extra leg
                 result["bm4dnet"] = {"error": repr(e)}
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
 
     if dist is not None:
         dist.barrier()
