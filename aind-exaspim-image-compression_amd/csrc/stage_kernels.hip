@@ -82,6 +82,9 @@ __device__ __forceinline__ void haar_inv(f16v& v) {
     }
 }
 
+#ifndef EXABM4D_GATHER_AUX
+#define EXABM4D_GATHER_AUX 0     // cache-policy bits of the gathers' buffer loads (A/B builds: 1 = sc0, 2 = nt, 3 = both)
+#endif
 // Issue the gather of one block (corner `src`) in layout L1 (hi = z, lo = x, regs y).
 __device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy, size_t sz, int hi,
                                         int lo, float (&v)[8]) {
@@ -109,7 +112,7 @@ __device__ __forceinline__ void gather8v(__amdgpu_buffer_rsrc_t rsrc, int corner
                                          float (&v)[8]) {
 #pragma unroll
     for (int y = 0; y < 8; y++)
-        v[y] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[y], corner, 0));
+        v[y] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[y], corner, EXABM4D_GATHER_AUX));
 }
 
 typedef float f32v __attribute__((ext_vector_type(32)));
@@ -153,7 +156,7 @@ __device__ __forceinline__ void gather8v2(__amdgpu_buffer_rsrc_t rsrc, int corne
                                           float (&a)[8], float (&b)[8]) {
 #pragma unroll
     for (int y = 0; y < 8; y++) {
-        const u2v t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(2u * voff[y]), corner2, 0);
+        const u2v t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(2u * voff[y]), corner2, EXABM4D_GATHER_AUX);
         a[y] = __uint_as_float(t.x);
         b[y] = __uint_as_float(t.y);
     }
