@@ -661,6 +661,17 @@ __global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
 #ifndef EXABM4D_WIE_NPL
 #define EXABM4D_WIE_NPL 22
 #endif
+#ifndef EXABM4D_WIE_PAIR_SAME_SIMD
+#define EXABM4D_WIE_PAIR_SAME_SIMD 0           // 1 (A/B builds): the two waves of a Wiener pair share a SIMD (waves w, w + 4)
+#endif
+// Which waves form a pair.  Default: neighbours (w, w ^ 1) -- consecutive wave ids go to different SIMDs.
+// SAME_SIMD (8-wave workgroups only): w and w + 4 land on the same SIMD.
+template <bool SAME>
+struct PairMap {
+    static __device__ __forceinline__ int half(int w) { return SAME ? (w >> 2) & 1 : w & 1; }
+    static __device__ __forceinline__ int partner(int w) { return SAME ? w ^ 4 : w ^ 1; }
+    static __device__ __forceinline__ int pair(int w) { return SAME ? (w & 3) : w >> 1; }
+};
 template <int NW_, int TY_, int TX_, int NPL_, bool HALFTB_ = false>
 struct HalfGeom {
     static constexpr bool HALFTB = HALFTB_;             // one pair component at a time through a float buffer
@@ -886,7 +897,8 @@ __device__ __forceinline__ bool process_half_group(
     constexpr int NP = WIENER ? 8 : 4;         // f2 values per lane swapped with the partner
     const int hi = lane >> 3, lo = lane & 7;
     STAMP(t0);
-    const int half = wave & 1, partner = wave ^ 1;
+    using PM = PairMap<WIENER && EXABM4D_WIE_PAIR_SAME_SIMD && HalfCfg<WIENER>::NW == 8>;
+    const int half = PM::half(wave), partner = PM::partner(wave);
     const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
     const int count = __popcll(__ballot(mykey != KEY_EMPTY));
     int K = 1;
@@ -1299,7 +1311,8 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     // readfirstlane: the wave index steers register indexing below and must be provably uniform
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * C::TBW);
-    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + (wave ^ 1) * C::TBW);
+    using PM = PairMap<WIENER && EXABM4D_WIE_PAIR_SAME_SIMD && C::NW == 8>;
+    f2* partner_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + PM::partner(wave) * C::TBW);
     int* lock = reinterpret_cast<int*>(lds + 2 * HNPL * HPS + HNW * C::TBW);
     int* sync = lock + 4;                                  // ready[HNW], ack[HNW]
     int* cnt = sync + 2 * HNW;                             // reports per layer (slot = layer & 7)
@@ -1338,7 +1351,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     }
     __syncthreads();
 
-    const int pairid = wave >> 1;
+    const int pairid = PM::pair(wave);
     int seq = 0;
     int seen = 0;           // last value read of lock[1] (layers retired), see the per-block gate
     const Dct7& tab = T;
