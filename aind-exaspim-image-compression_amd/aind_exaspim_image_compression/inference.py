@@ -51,6 +51,22 @@ def tune_model(model):
     return model
 
 
+def quick_start(model):
+    """Opt-in for ONE-OFF volumes on a fresh process: NDHWC weights + MIOpen's FAST find mode
+    (``MIOPEN_FIND_MODE=2``, set here unless the caller set the variable; it must happen before the
+    process runs its first convolution).  MIOpen's default find mode spends 17 s on the first U-Net
+    batch of a process (kernel selection by timing); FAST mode picks by heuristics in 0.2 s.  Measured on
+    an MI355X, U-Net forward 32 x 64^3 fp32 (tools/dbg/miopen_modes.py): default mode, default layout:
+    first call 16.8 s, then 117 ms; FAST + NDHWC: first call 0.2 s, then 122 ms; FAST with the default
+    layout falls on a slow solver (316 ms) -- hence both halves here.  For one 1024^3 volume (250
+    batches) that is 31 s instead of 46 s; for long jobs ``tune_model`` (39 s search, then 70 ms) wins.
+    Same fp32 arithmetic in all three; results differ by summation order only."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    if isinstance(model, torch.nn.Module):
+        model.to(memory_format=torch.channels_last_3d)
+    return model
+
+
 def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, trim=5,
             verbose=True):
     """Denoise a 3-D image by overlapping-patch inference; returns uint16 counts.

@@ -149,6 +149,21 @@ def test_predict_with_unet_and_predict_patch():
     assert np.mean(np.abs(a - b) > 1) < 1e-3
 
 
+def test_quick_start_and_tune_model_give_the_same_volume():
+    """The two opt-in MIOpen recipes (inference.quick_start: NDHWC + FAST find mode for one-off volumes;
+    inference.tune_model: NDHWC + exhaustive search for long jobs) change solvers, not arithmetic:
+    predict() returns the default model's volume up to fp32 summation order (<= 1 count, rarely)."""
+    tf = T.build_transform(TF_CFG)
+    vol = tiling_volume((64, 116, 116), seed=4)
+    outs = []
+    for prep in (lambda m: m, inference.quick_start):
+        torch.manual_seed(0)
+        model = prep(unet3d.UNet().cuda().eval())
+        outs.append(inference.predict(vol, model, tf, batch_size=4, verbose=False).astype(np.int32))
+    d = np.abs(outs[0] - outs[1])
+    assert d.max() <= 1 and np.mean(d > 0) < 1e-2
+
+
 def test_chunk_byte_histograms_and_cratio(ctx):
     """Row f-1 front end: per-chunk byte-plane histograms (integer-exact vs numpy), the entropy
     rate proxy, and compute_cratio's chunk walk with a stand-in codec."""
