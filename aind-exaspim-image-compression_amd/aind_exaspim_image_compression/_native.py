@@ -109,6 +109,7 @@ SIGNATURES = {
     "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_chunked_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, _F, _F, _PP,
                                              _I]),
+    "exabm4d_denoise_chunked_u16_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
     "exabm4d_transform_forward_f32_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
@@ -411,6 +412,16 @@ class Context:
             self.handle, _ptr(src), _ptr(dst), nz, ny, nx, int(zc0), int(zc1), int(chunk),
             int(halo), float(sigma), float(offset), ctypes.byref(p), int(stages)))
 
+    def denoise_chunked_u16_host(self, src, dst, sigma, offset, chunk=256, halo=8, params=None, stages=2):
+        """Host uint16 arrays (numpy / memmap, C-contiguous, same 3-D shape) streamed through the device
+        one layer of chunks at a time; returns when ``dst`` is complete."""
+        p = params or default_params()
+        check_host_volume_pair(src, dst)
+        nz, ny, nx = src.shape
+        self._check(lib().exabm4d_denoise_chunked_u16_host(
+            self.handle, src.ctypes.data, dst.ctypes.data, nz, ny, nx, int(chunk), int(halo), float(sigma),
+            float(offset), ctypes.byref(p), int(stages)))
+
     def denoise_f32_host(self, arr, sigma, params=None, stages=2, clip=None):
         """numpy fp32 [N,]Z,Y,X in -> new numpy array out (H2D, kernels, D2H, sync)."""
         p = params or default_params()
@@ -594,6 +605,19 @@ def context(device=None):
             if _hip_owner_pid is None:
                 _hip_owner_pid = os.getpid()
     return ctx
+
+
+def check_host_volume_pair(src, dst):
+    """What exabm4d_denoise_chunked_u16_host needs of its two host arrays (raises ValueError)."""
+    for a in (src, dst):
+        if not isinstance(a, np.ndarray) or a.ndim != 3 or a.dtype != np.uint16 or not a.flags.c_contiguous:
+            raise ValueError("3-D C-contiguous uint16 arrays expected")
+    if src.shape != dst.shape:
+        raise ValueError("source and destination differ in shape")
+    if not dst.flags.writeable:
+        raise ValueError("the destination is read-only")
+    if np.shares_memory(src, dst):
+        raise ValueError("source and destination may not overlap")
 
 
 def device_count():

@@ -135,3 +135,26 @@ def denoise_chunked(vol_u16, sigma, offset=0.0, chunk=256, halo=8, profile=None,
     finally:
         d_in.free()
         d_out.free()
+
+
+def denoise_chunked_streamed(vol_u16, sigma, offset=0.0, chunk=256, halo=8, profile=None, stages=2,
+                             device=None, out=None):
+    """``denoise_chunked`` for volumes that should not (or cannot) sit on the device whole -- the
+    reference's production harness denoises whole images (scripts/evaluate_bm4dnet.py:51-181), and
+    BASELINE config 4's tile is 64 GiB.  ``vol_u16`` is a C-contiguous uint16 array or ``np.memmap``;
+    layers of chunks travel up, are denoised chunk by chunk in isolation and travel down while the
+    next layer is in the kernels (``exabm4d_denoise_chunked_u16_host``).  ``out`` may name the
+    destination (another array / writeable memmap of the same shape); the result equals
+    ``denoise_chunked`` on the whole volume."""
+    vol = vol_u16 if isinstance(vol_u16, np.ndarray) and vol_u16.dtype == np.uint16 and \
+        vol_u16.flags.c_contiguous else np.ascontiguousarray(vol_u16, dtype=np.uint16)
+    if vol.ndim != 3:
+        raise ValueError("denoise_chunked_streamed expects a 3-D uint16 volume")
+    if out is None:
+        out = np.empty(vol.shape, dtype=np.uint16)
+    _native.check_host_volume_pair(vol, out)
+    prof = profile or BM4DProfile()
+    ctx = _native.context(device)
+    ctx.denoise_chunked_u16_host(vol, out, float(sigma), float(offset), chunk=int(chunk), halo=int(halo),
+                                 params=prof.native(), stages=int(stages))
+    return out

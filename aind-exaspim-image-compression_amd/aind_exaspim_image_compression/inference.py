@@ -59,7 +59,7 @@ def quick_start(model):
     an MI355X, U-Net forward 32 x 64^3 fp32 (tools/dbg/miopen_modes.py): default mode, default layout:
     first call 16.8 s, then 117 ms; FAST + NDHWC: first call 0.2 s, then 122 ms; FAST with the default
     layout falls on a slow solver (316 ms) -- hence both halves here.  For one 1024^3 volume (250
-    batches) that is 31 s instead of 46 s; for long jobs ``tune_model`` (39 s search, then 70 ms) wins.
+    batches), measured on a fresh process: 30.7 s against 43.5 s (tools/dbg/quick_start_1024.py); for long jobs ``tune_model`` (39 s search, then 70 ms) wins.
     Same fp32 arithmetic in all three; results differ by summation order only."""
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     if isinstance(model, torch.nn.Module):

@@ -4,9 +4,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/exabm4d.h"
@@ -814,6 +817,146 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                     HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
                 }
             }
+    return EXABM4D_OK;
+}
+
+// ---- chunk-local mode, host volume streamed through the device ------------------------------------
+// A host volume of any size (BASELINE config 4's tile is 64 GiB of uint16) goes through the device one
+// LAYER of chunks at a time: planes [k chunk - halo, (k + 1) chunk + halo) up, cores down.  Two
+// device windows and two result buffers; an uploader and a downloader thread (plain copies on their
+// own streams: the host side of a pageable copy blocks, so each direction gets a thread) run one layer
+// ahead of / behind exabm4d_denoise_chunked_u16_dev on the context's stream.  Chunks are independent
+// units, so the result is the one-call result of exabm4d_denoise_chunked_u16_dev on the whole volume.
+namespace {
+struct StreamedLayers {
+    std::mutex m;
+    std::condition_variable cv;
+    int uploaded = 0;       // layers whose window is on the device
+    int enqueued = 0;       // layers whose compute has been enqueued (comp_ev[k & 1] recorded)
+    int downloaded = 0;     // layers whose cores are back in the caller's array
+    bool failed = false;
+    std::string err;
+
+    void advance(int StreamedLayers::*field) {
+        { std::lock_guard<std::mutex> l(m); (this->*field)++; }
+        cv.notify_all();
+    }
+    bool wait_for(int StreamedLayers::*field, int value) {      // false: somebody failed
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return failed || this->*field >= value; });
+        return !failed;
+    }
+    void fail_with(const std::string& what) {
+        { std::lock_guard<std::mutex> l(m); if (!failed) { failed = true; err = what; } }
+        cv.notify_all();
+    }
+};
+}  // namespace
+
+int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
+                                     int nx, int chunk, int halo, float sigma, float offset,
+                                     const exabm4d_params* p, int stages) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    int rc = check_params(ctx, p);
+    if (rc) return rc;
+    if (!(sigma > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma must be > 0");
+    if (stages != 1 && stages != 2) return fail(ctx, EXABM4D_ERR_INVALID, "stages must be 1 or 2");
+    if (nz < 1 || ny < 1 || nx < 1 || chunk < 1 || halo < 0 || halo > 64)
+        return fail(ctx, EXABM4D_ERR_INVALID, "chunked: sizes >= 1, chunk >= 1, 0 <= halo <= 64");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int layers = (nz + chunk - 1) / chunk;
+    const size_t plane = (size_t)ny * (size_t)nx;
+    const int wmax = std::min(nz, chunk + 2 * halo), cmax = std::min(nz, chunk);
+    const int device = ctx->device;
+
+    uint16_t* win[2] = {nullptr, nullptr};
+    uint16_t* res[2] = {nullptr, nullptr};
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    hipEvent_t comp_ev[2] = {nullptr, nullptr};
+    const int nbuf = layers > 1 ? 2 : 1;
+    auto release = [&]() {
+        for (int i = 0; i < 2; i++) {
+            if (win[i]) (void)hipFree(win[i]);
+            if (res[i]) (void)hipFree(res[i]);
+            if (comp_ev[i]) (void)hipEventDestroy(comp_ev[i]);
+        }
+        if (s_up) (void)hipStreamDestroy(s_up);
+        if (s_down) (void)hipStreamDestroy(s_down);
+    };
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < nbuf && e == hipSuccess; i++) {
+        e = hipMalloc((void**)&win[i], (size_t)wmax * plane * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&res[i], (size_t)cmax * plane * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&comp_ev[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        release();
+        return fail_hip(ctx, e, "streamed chunk mode: device windows / streams");
+    }
+
+    StreamedLayers st;
+    auto window_of = [&](int k, int& w0, int& w1, int& c0, int& c1) {
+        c0 = k * chunk;
+        c1 = std::min(nz, c0 + chunk);
+        w0 = std::max(0, c0 - halo);
+        w1 = std::min(nz, c1 + halo);
+    };
+    std::thread uploader([&]() {
+        if (hipSetDevice(device) != hipSuccess) return st.fail_with("uploader: hipSetDevice");
+        for (int k = 0; k < layers; k++) {
+            if (k >= 2) {       // window k & 1 was read by layer k - 2
+                if (!st.wait_for(&StreamedLayers::enqueued, k - 1)) return;
+                if (hipEventSynchronize(comp_ev[k & 1]) != hipSuccess) return st.fail_with("uploader: hipEventSynchronize");
+            }
+            int w0, w1, c0, c1;
+            window_of(k, w0, w1, c0, c1);
+            hipError_t r = hipMemcpyAsync(win[k & 1], in + (size_t)w0 * plane, (size_t)(w1 - w0) * plane * sizeof(uint16_t),
+                                          hipMemcpyHostToDevice, s_up);
+            if (r == hipSuccess) r = hipStreamSynchronize(s_up);
+            if (r != hipSuccess) return st.fail_with(std::string("upload of a chunk layer: ") + hipGetErrorString(r));
+            st.advance(&StreamedLayers::uploaded);
+        }
+    });
+    std::thread downloader([&]() {
+        if (hipSetDevice(device) != hipSuccess) return st.fail_with("downloader: hipSetDevice");
+        for (int k = 0; k < layers; k++) {
+            if (!st.wait_for(&StreamedLayers::enqueued, k + 1)) return;
+            int w0, w1, c0, c1;
+            window_of(k, w0, w1, c0, c1);
+            hipError_t r = hipEventSynchronize(comp_ev[k & 1]);
+            if (r == hipSuccess)
+                r = hipMemcpyAsync(out + (size_t)c0 * plane, res[k & 1], (size_t)(c1 - c0) * plane * sizeof(uint16_t),
+                                   hipMemcpyDeviceToHost, s_down);
+            if (r == hipSuccess) r = hipStreamSynchronize(s_down);
+            if (r != hipSuccess) return st.fail_with(std::string("download of a chunk layer: ") + hipGetErrorString(r));
+            st.advance(&StreamedLayers::downloaded);
+        }
+    });
+
+    std::string compute_err;
+    for (int k = 0; k < layers; k++) {
+        // the window is up; the result buffer k & 1 (layer k - 2's) has been fetched
+        if (!st.wait_for(&StreamedLayers::uploaded, k + 1) || !st.wait_for(&StreamedLayers::downloaded, k - 1)) break;
+        int w0, w1, c0, c1;
+        window_of(k, w0, w1, c0, c1);
+        rc = exabm4d_denoise_chunked_u16_dev(ctx, win[k & 1], res[k & 1], w1 - w0, ny, nx, c0 - w0, c1 - w0, chunk,
+                                             halo, sigma, offset, p, stages);
+        hipError_t r = rc ? hipSuccess : hipEventRecord(comp_ev[k & 1], ctx->stream);
+        if (rc || r != hipSuccess) {
+            compute_err = rc ? ctx->err : std::string("hipEventRecord: ") + hipGetErrorString(r);
+            if (!rc) rc = EXABM4D_ERR_HIP;
+            st.fail_with(compute_err);
+            break;
+        }
+        st.advance(&StreamedLayers::enqueued);
+    }
+    uploader.join();
+    downloader.join();
+    (void)hipStreamSynchronize(ctx->stream);
+    release();
+    if (st.failed) return fail(ctx, rc ? rc : EXABM4D_ERR_HIP, "streamed chunk mode: " + st.err);
     return EXABM4D_OK;
 }
 

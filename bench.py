@@ -452,15 +452,19 @@ def run_chunks(args, rank, local_rank, world, dist):
     import torch
     from aind_exaspim_image_compression.distributed import (ChunkedSlabDenoiser, denoise_chunked_slab,
                                                             plan_chunk_slabs)
-    n, chunk, halo = args.size, args.chunk, 8
-    shape = (n * world, n, n)
+    chunk, halo = args.chunk, 8
+    # per-rank planes x rows x columns: --size^3 unless --shape names them (BASELINE config 4's share of
+    # one rank of eight is --shape 256,4096,4096: the whole tile is 2048 x 4096 x 4096)
+    pz, py, px = (args.size,) * 3 if not args.shape else tuple(int(v) for v in args.shape.split(","))
+    shape = (pz * world, py, px)
     plan = plan_chunk_slabs(shape[0], world, rank, chunk=chunk, halo=halo)
     dev = torch.device("cuda", local_rank)
     host = synth_u16(shape, seed=3000, z_range=(plan.z0, plan.z1))
     own = torch.from_numpy(host.view(np.int16)).to(dev)
-    raw = torch.zeros((plan.p1 - plan.p0, n, n), dtype=torch.int16, device=dev)
+    del host
+    raw = torch.zeros((plan.p1 - plan.p0, py, px), dtype=torch.int16, device=dev)
     den = ChunkedSlabDenoiser(SIGMA, OFFSET, dev, chunk=chunk, halo=halo)
-    own_shape = (plan.z1 - plan.z0, n, n)
+    own_shape = (plan.z1 - plan.z0, py, px)
     encode, sz16 = torch_encode_legs(den.ctx, own_shape, dev)
 
     def step():
@@ -494,11 +498,11 @@ def run_chunks(args, rank, local_rank, world, dist):
                 (own[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float()
         emit(json.dumps({
             "metric": "denoised+encoded voxels/s on 1024^3 uint16",
-            "value": world * n ** 3 * args.steps / elapsed,
+            "value": world * pz * py * px * args.steps / elapsed,
             "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{shape[0]}x{n}x{n} uint16 volume, chunk-local two-stage BM4D: "
+            "config": {"workload": f"{shape[0]}x{py}x{px} uint16 volume, chunk-local two-stage BM4D: "
                                    f"{chunk}^3 cores + {halo}-voxel halo, {world} z-slab(s) of whole "
                                    "chunk layers, raw-input halo exchange overlapped with interior layers",
                        "volume": list(shape), "stages": 2,
@@ -582,6 +586,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024, help="cubic volume edge per GPU")
     ap.add_argument("--stages", type=int, default=2)
     ap.add_argument("--chunk", type=int, default=256, help="core edge of --mode chunks")
+    ap.add_argument("--shape", default="", help="--mode chunks: planes,rows,columns PER RANK instead of --size^3 "
+                                                "(256,4096,4096 on 8 ranks is BASELINE config 4's tile)")
     ap.add_argument("--mode", choices=["volumes", "slabs", "chunks"], default="volumes",
                     help="N>1 sharding: 'volumes' = one independent volume per rank, no "
                          "data-path collective (default); 'slabs' = one (N*size) x size x size "

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXABM4D_VERSION 300 /* 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
+#define EXABM4D_VERSION 301 /* 0.3.1: + exabm4d_denoise_chunked_u16_host; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
 
 typedef enum exabm4d_status {
     EXABM4D_OK = 0,
@@ -232,6 +232,19 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
 int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
                                     int nx, int zc0, int zc1, int chunk, int halo, float sigma,
                                     float offset, const exabm4d_params* p, int stages);
+/* Chunk-local mode on a HOST volume of any size, streamed through the device (the harness shape of
+ * scripts/evaluate_bm4dnet.py:51-181 -- a whole image in, a whole image out -- at BASELINE config 4's
+ * tile size, 64 GiB of uint16, which no device call above takes in one piece).  `in` and `out` are
+ * host arrays [nz][ny][nx] (pageable or pinned; they may not overlap).  One LAYER of chunks at a time:
+ * planes [k chunk - halo, (k + 1) chunk + halo) go up, exabm4d_denoise_chunked_u16_dev runs on them
+ * on the context's stream, the cores come down; an uploader and a downloader thread inside the call
+ * keep the copies of layer k + 1 and k - 1 under the kernels of layer k.  Device memory: two windows
+ * of (chunk + 2 halo) planes, two results of chunk planes, plus the scratch of the device call.  The
+ * result is that of exabm4d_denoise_chunked_u16_dev on the whole volume (chunks are independent).
+ * Blocks until `out` is complete. */
+int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
+                                     int nx, int chunk, int halo, float sigma, float offset,
+                                     const exabm4d_params* p, int stages);
 /* Host-pointer form of exabm4d_denoise_f32_dev (the bm4d(z, sigma) shim calls this). */
 int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
                              int batch, float sigma, const exabm4d_params* p, int stages,

@@ -84,6 +84,16 @@ def test_gpus_flag_launches_its_own_ranks(mode):
 
 
 @pytest.mark.gpu
+def test_chunks_mode_takes_a_per_rank_shape():
+    """--shape planes,rows,columns: the layout BASELINE config 4 runs at (256,4096,4096 per rank); here
+    one rank, one layer of 2 x 3 chunks of 32^3."""
+    d = _run("--mode", "chunks", "--chunk", "32", "--shape", "32,64,96")
+    assert d["config"]["volume"] == [32, 64, 96]
+    assert abs(d["value"] - 32 * 64 * 96 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert 15.0 < d["residual_std"] < 30.0 and d["rank0_lossless_cratio"] > 1.0
+
+
+@pytest.mark.gpu
 def test_a_failing_rank_fails_the_launcher():
     env = dict(os.environ, BENCH_REHEARSAL="1", BENCH_FAIL_RANK="1")
     env.pop("WORLD_SIZE", None)

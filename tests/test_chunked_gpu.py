@@ -119,3 +119,45 @@ def test_config4_geometry_256_cores_plus_8(ctx):
     assert near.max() > 0                             # the cut is real: chunk-local semantics, not a no-op
     peak = float(cl.max() - cl.min())
     assert abs(psnr(whole, cl, peak) - psnr(chunked, cl, peak)) < 0.1
+
+
+def test_streamed_host_volume_equals_the_one_call_result(ctx, oracle, tmp_path):
+    """exabm4d_denoise_chunked_u16_host: the volume goes through the device one layer of chunks at a
+    time (here 16 + 16 + 8 planes: three layers, the last one ragged, windows cut at both ends),
+    copies of the neighbouring layers under the kernels.  Same chunks, same pipeline: the oracle's
+    chunk-local result within a count, and the one-call device result."""
+    from aind_exaspim_image_compression.bm4d import denoise_chunked_streamed
+    vol, _ = synth_volume((40, 36, 44), seed=21, as_u16=True)
+    want = oracle.bm4d_u16_chunked(vol, SIGMA, OFFSET, 16, 4)
+    got = denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=16, halo=4)
+    assert got.dtype == np.uint16 and got.shape == vol.shape
+    close_u16(got, want)
+    close_u16(got, denoise_chunked(vol, SIGMA, OFFSET, chunk=16, halo=4))
+    # file-backed source and destination (a raw tile on disk in, a raw tile on disk out)
+    src = np.memmap(tmp_path / "in.u16", dtype=np.uint16, mode="w+", shape=vol.shape)
+    src[:] = vol
+    src.flush()
+    src = np.memmap(tmp_path / "in.u16", dtype=np.uint16, mode="r", shape=vol.shape)
+    dst = np.memmap(tmp_path / "out.u16", dtype=np.uint16, mode="w+", shape=vol.shape)
+    assert denoise_chunked_streamed(src, SIGMA, OFFSET, chunk=16, halo=4, out=dst) is dst
+    dst.flush()
+    close_u16(np.fromfile(tmp_path / "out.u16", dtype=np.uint16).reshape(vol.shape), want)
+    # one layer only (no second window), one stage, and a layer count that is odd / even
+    one = denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=64, halo=0)
+    np.testing.assert_array_equal(one, denoise_volume(vol, SIGMA, OFFSET))
+    close_u16(denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=8, halo=8, stages=1),
+              denoise_chunked(vol, SIGMA, OFFSET, chunk=8, halo=8, stages=1))
+
+
+def test_streamed_host_volume_errors(ctx):
+    from aind_exaspim_image_compression.bm4d import denoise_chunked_streamed
+    vol, _ = synth_volume((24, 24, 24), seed=2, as_u16=True)
+    with pytest.raises(ValueError):
+        denoise_chunked_streamed(vol, SIGMA, OFFSET, out=vol)                       # in place
+    with pytest.raises(ValueError):
+        denoise_chunked_streamed(vol, SIGMA, OFFSET, out=np.empty((24, 24, 25), np.uint16))
+    with pytest.raises((ValueError, RuntimeError)):
+        denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=4, halo=1)               # padded chunk thinner than a block
+    # the context is usable afterwards
+    close_u16(denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=16, halo=8),
+              denoise_chunked(vol, SIGMA, OFFSET, chunk=16, halo=8))
