@@ -25,7 +25,7 @@ struct __attribute__((packed, aligned(4))) float4u {
 };
 
 constexpr int TCZ = 8;       // cell layers per tile = waves per workgroup
-// (TCZ cell layers give TCZ - 1 reference layers; the march below carries the eighth across blocks)
+constexpr int TRZ = TCZ - 1; // reference layers per tile
 constexpr int NE = 6;        // dy values per pass (two passes: dy = -5..0 and 1..6, 6 is masked)
 constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
 // A wave is one z-layer of TCY x TCX cells (64 lanes).  8 x 8 is the shape for volumes; 4 x 16
@@ -47,40 +47,6 @@ struct TileShape {
     static_assert(TCY * TCX == 64 && PCOLS % 4 == 0 && PSTR % 4 == 0, "one wave per cell layer");
 };
 
-// MARCH (round 3): a workgroup no longer stops after one tile of eight cell layers.  A reference
-// block is two cell layers, so eight layers give seven reference layers and every eighth layer is
-// computed twice (once as the top layer of a tile, once as the bottom layer of the next): 296 layer
-// slots for the 255 reference layers of a 1024^3 volume.  Now a workgroup marches up a SEGMENT of
-// `nblk` blocks of eight cell layers: wave w of block b computes cell layer L = Ls + 8 b + w and owns
-// the reference layer L - 1 -- its lower cells are wave w - 1's (LDS, as before), and for wave 0 of
-// b > 0 they are the sums wave 7 formed in block b - 1, which go through a per-workgroup carry buffer
-// in global memory (33 sums x 64 cells per exchange round, written after the round's second barrier,
-// read one block later: L2-resident, a fraction of a per cent of the kernel's traffic).  A segment
-// yields 8 nblk - 1 reference layers from 8 nblk cell layers; the same sums enter the same adds, so
-// tables are unchanged.  nblk = 1 is the old tiling.  Carry slots are claimed from a small pool with a
-// CAS (at most one workgroup per CU is resident: 147 KB of LDS), released at the end.
-constexpr int CARRY_ROUND = (NE / 2) * SWIN * 64;          // elements of one exchange round (33 x 64)
-constexpr int CARRY_SLOT = (NSTEP / 4) * 2 * CARRY_ROUND + 64;   // 22 (dz, pass) x 2 rounds, + overhang
-constexpr int CARRY_SLOTS = 512;
-struct March {
-    int nblk;                // blocks of eight cell layers per segment
-    int flags;               // timing probes (wrong tables): 1 = wave 0 skips the carry read, 2 = wave 7 skips the write
-    uint32_t* carry;         // [CARRY_SLOTS][CARRY_SLOT]
-    int* locks;              // [CARRY_SLOTS], zero when free
-};
-__device__ inline int march_claim_slot(const March& m, int* slot_s) {
-    if (m.nblk > 1) {
-        if (threadIdx.x == 0) {
-            int sidx = (int)(blockIdx.x % CARRY_SLOTS);
-            while (atomicCAS(m.locks + sidx, 0, 1) != 0) sidx = (sidx + 1) % CARRY_SLOTS;
-            *slot_s = sidx;
-        }
-        __syncthreads();
-        return *slot_s;
-    }
-    return 0;
-}
-
 // Each WAVE (= one z-layer of 8x8 cells) streams the candidate planes it needs through its own
 // pair of LDS buffers: for a fixed dz and a pass of NE dy values, plane z+dz of the volume
 // (37 rows x 44 columns around the tile) is staged once and serves all 4 x NE x 11 (row, dy, dx)
@@ -95,36 +61,28 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
-                                                      int tiles_x, int guarded, March march) {
+                                                      int tiles_x, int guarded) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS,
                   PCOLS = TS::PCOLS, PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) float pbuf_all[TCZ][2][PBUF];
-    __shared__ float lower0[CARRY_ROUND + 64];          // wave 0's lower cell layer of blocks > 0 (from the carry)
-    __shared__ int slot_s;
 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
 
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, ts = tile / (tiles_x * tiles_y);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int cx = lane % TCX, cy = lane / TCX, cz = __builtin_amdgcn_readfirstlane(tid >> 6);   // cz == wave index
-    const int ix = TRX * tx + cx, iy = TRY * ty + cy;                 // cell == ref index in y, x
+    const int cx = lane % TCX, cy = lane / TCX, cz = tid >> 6;       // cz == wave index
+    const int ix = TRX * tx + cx, iy = TRY * ty + cy, iz = TRZ * tz + cz;  // cell == ref index
 
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
-    // segment of the march (see bm_tile16_kernel's header): reference layers [Ls, Ls + rseg)
-    const int RSEG = TCZ * march.nblk - 1;
-    const int Ls = ts * RSEG;
-    const int rseg = min(RSEG, g.az - Ls);
-    const int nb = (rseg + TCZ) / TCZ;
-    float* carry = reinterpret_cast<float*>(march.carry) + (size_t)march_claim_slot(march, &slot_s) * CARRY_SLOT;
-
     // Cell origin; cells beyond the volume are clamped inside it (their sums are never used).
-    const int qy = min(STEP * iy, g.ny - STEP), qx = min(STEP * ix, g.nx - STEP);
+    const int qz = min(STEP * iz, g.nz - STEP), qy = min(STEP * iy, g.ny - STEP),
+              qx = min(STEP * ix, g.nx - STEP);
     // Tile origin (voxels) of the staged window; wave-uniform.
-    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD;
+    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD, Z0 = STEP * (TRZ * tz + cz);
     // Whole staged column range inside the volume?  (wave-uniform; edge tiles clamp per element.)
     // `guarded`: the volume is one of the library's own buffers, with >= 256 bytes of mapped memory
     // on either side.  Columns outside the volume then need no clamping at all: they only ever
@@ -133,32 +91,18 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // LDS-DMA path too and read whatever lies beyond the row ends.
     const bool xin = guarded || ((X0 >= 0) && (X0 + PCOLS - 1 <= g.nx - 1));
 
-    const bool ref_yx = cx < TRX && cy < TRY && iy < g.ay && ix < g.ax;
-    const int ry = STEP * iy, rx = STEP * ix;
-
-    // bit d set iff candidate displacement dx = d - 5 keeps the block inside the volume
-    uint32_t xmask = 0;
-#pragma unroll
-    for (int d = 0; d < SWIN; d++)
-        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
-
-    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
-#pragma unroll 1
-    for (int blk = 0; blk < nb; blk++) {
-    const int L = Ls + TCZ * blk + cz;                 // this wave's cell layer in this block
-    const bool active = L <= g.az;
-    const int iz = L - 1;                              // the reference layer it owns (lower cells: wave cz - 1)
-    const int qz = min(STEP * L, g.nz - STEP);
-    const int Z0 = STEP * L;
-    const bool ref_ok = ref_yx && active && (blk > 0 || cz > 0);
-    const bool lower_carried = cz == 0;
-    const bool carries = cz == TCZ - 1 && blk + 1 < nb;
-    const int rz = STEP * iz;
+    const bool ref_ok = cx < TRX && cy < TRY && cz < TRZ && iz < g.az && iy < g.ay && ix < g.ax;
+    const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
 
     uint32_t list[MAXG];
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
     uint32_t thr = keymax;       // min(list[15], keymax): a key below it enters the list
+    // bit d set iff candidate displacement dx = d - 5 keeps the block inside the volume
+    uint32_t xmask = 0;
+#pragma unroll
+    for (int d = 0; d < SWIN; d++)
+        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
 
     auto step_plane = [&](int step, int& dylo) -> const float* {
         const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
@@ -173,6 +117,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // the row of a chunk needs no clamp, so its source is a wave-uniform base (plane, first row,
     // first column) plus a lane constant r * sy + 4 q -- eight instructions per DMA instead of the
     // thirty of the clamped form (a fifth of a step's instructions went into these addresses).
+    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
     auto issue_dma = [&](int step, float* dst) {
         int dylo;
         const float* plane = step_plane(step, dylo);
@@ -218,9 +163,9 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // A wave whose cell layer lies beyond the last one any reference block uses (layers 0 .. az)
     // has nothing to contribute -- the last z tile of a 64^3 patch needs 2 of its 8 layers -- and
     // only keeps the workgroup's barrier count: four per (dz, pass).
-    if (!active) {
+    if (TRZ * tz + cz > g.az) {
         for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
-        continue;
+        return;
     }
 
     if (xin)
@@ -305,10 +250,8 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             // exchange slot of cell (wave w, local l), displacement d: pbuf_all[w][cur][64 d + l]
             const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
             float* mine = cur + lane;
-            const float* up_w = cur + lane;                                  // own cells: the upper layer
-            // the lower layer: wave cz - 1's sums; for wave 0 the previous block's top layer
-            const float* lo_w = (cz > 0 ? pbuf_all[max(cz - 1, 0)][step & 1] : lower0) + lane;
-            float* cslot = carry + (size_t)((step >> 2) * 2) * CARRY_ROUND + lane;
+            const float* lo_w = cur + lane;                                  // cells of wave cz
+            const float* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;  // wave cz + 1
             // NE / 2 dy values per round (33 sums per cell fit the 36 slots of a plane buffer):
             // two barrier pairs per pass instead of six.  Each cell lane first adds its
             // x-neighbour's sum (DPP row_shl:1, no LDS), so a reference lane reads 4 values per
@@ -323,11 +266,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                             0, __float_as_int(acc[e][d]), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
                         mine[64 * ((e - e0) * SWIN + d)] = acc[e][d] + right;
                     }
-                if (lower_carried && blk > 0 && !(march.flags & 1)) {
-#pragma unroll
-                    for (int k = 0; k < (NE / 2) * SWIN; k++)
-                        lower0[64 * k + lane] = cslot[(e0 ? CARRY_ROUND : 0) + 64 * k];
-                }
                 __syncthreads();
                 if (ref_ok) {
 #pragma unroll
@@ -341,7 +279,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 #pragma unroll
                             for (int d = 0; d < SWIN; d++) {
                                 const float* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
-                                const float* c1 = up_w + 64 * ((e - e0) * SWIN + d);
+                                const float* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
                                 // S = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]) as three plain adds: left
                                 // to the SLP vectoriser this becomes two packed adds, three moves and
                                 // two wait states
@@ -364,18 +302,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                     }
                 }
                 __syncthreads();
-                if (carries && !(march.flags & 2)) {
-                    // the top wave's sums are the next block's lowest layer (read there by wave 0 in
-                    // this same round, i.e. before this slot is written again)
-#pragma unroll
-                    for (int e = e0; e < e0 + NE / 2; e++)
-#pragma unroll
-                        for (int d = 0; d < SWIN; d++) {
-                            const float right = __int_as_float(__builtin_amdgcn_update_dpp(
-                                0, __float_as_int(acc[e][d]), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
-                            cslot[(e0 ? CARRY_ROUND : 0) + 64 * ((e - e0) * SWIN + d)] = acc[e][d] + right;
-                        }
-                }
             }
 #pragma unroll
             for (int e = 0; e < NE; e++)
@@ -394,12 +320,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
             *reinterpret_cast<uint4*>(out + k) = v;
         }
-    }
-    }   // blocks of the segment
-
-    if (march.nblk > 1) {
-        __syncthreads();
-        if (threadIdx.x == 0) atomicExch(march.locks + slot_s, 0);
     }
 }
 
@@ -445,62 +365,42 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restrict__ vol_all, VolGeom g,
                                                         uint32_t keymax,
                                                         uint32_t* __restrict__ keys_all, int tiles_y,
-                                                        int tiles_x, March march) {
+                                                        int tiles_x) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS, PCOLS = TS::PCOLS,
                   PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) uint32_t pbuf_all[TCZ][2][PBUF];
-    __shared__ uint32_t lower0[CARRY_ROUND + 64];       // wave 0's lower cell layer of blocks > 0 (from the carry)
-    __shared__ int slot_s;
 
     const uint16_t* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
 
     const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, ts = tile / (tiles_x * tiles_y);
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int cx = lane % TCX, cy = lane / TCX, cz = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ix = TRX * tx + cx, iy = TRY * ty + cy;
+    const int cx = lane % TCX, cy = lane / TCX, cz = tid >> 6;
+    const int ix = TRX * tx + cx, iy = TRY * ty + cy, iz = TRZ * tz + cz;
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
-    // segment: reference layers [Ls, Ls + rseg), cell layers Ls ... Ls + rseg
-    const int RSEG = TCZ * march.nblk - 1;
-    const int Ls = ts * RSEG;
-    const int rseg = min(RSEG, g.az - Ls);
-    const int nb = (rseg + TCZ) / TCZ;                 // blocks that hold rseg + 1 cell layers
-    uint32_t* carry = march.carry + (size_t)march_claim_slot(march, &slot_s) * CARRY_SLOT;
-
-    const int qy = min(STEP * iy, g.ny - STEP), qx = min(STEP * ix, g.nx - STEP);
+    const int qz = min(STEP * iz, g.nz - STEP), qy = min(STEP * iy, g.ny - STEP),
+              qx = min(STEP * ix, g.nx - STEP);
     // staged window: rows Y0 + dylo ..., columns X0 ... with X0 even (one column more to the left
     // than the search needs): cell cx finds candidate column x + d of its voxel x at staged
     // column 4 cx + 1 + x + d
-    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD - 1;
-    const int ry = STEP * iy, rx = STEP * ix;
-    const bool ref_yx = cx < TRX && cy < TRY && iy < g.ay && ix < g.ax;
+    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD - 1, Z0 = STEP * (TRZ * tz + cz);
 
-    uint32_t xmask = 0;
-#pragma unroll
-    for (int d = 0; d < SWIN; d++)
-        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
-    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
-
-#pragma unroll 1
-    for (int blk = 0; blk < nb; blk++) {
-    const int L = Ls + TCZ * blk + cz;                 // this wave's cell layer in this block
-    const bool active = L <= g.az;                     // cell layers 0 .. az exist
-    const int iz = L - 1;                              // ... and the reference layer it owns
-    const int qz = min(STEP * L, g.nz - STEP);
-    const int Z0 = STEP * L;
-    const bool ref_ok = ref_yx && active && (blk > 0 || cz > 0);
-    const bool lower_carried = cz == 0;                // (only read when blk > 0)
-    const bool carries = cz == TCZ - 1 && blk + 1 < nb;
-    const int rz = STEP * iz;
+    const bool ref_ok = cx < TRX && cy < TRY && cz < TRZ && iz < g.az && iy < g.ay && ix < g.ax;
+    const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
 
     uint32_t list[MAXG];
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
     uint32_t thr = keymax;
+    uint32_t xmask = 0;
+#pragma unroll
+    for (int d = 0; d < SWIN; d++)
+        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
 
+    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
     auto issue_dma = [&](int step, uint32_t* dst) {
         const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
         const int dylo = pass == 0 ? -RAD : 1;
@@ -522,11 +422,9 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         }
     };
 
-    if (!active) {
-        // a wave whose cell layer lies beyond the last one any reference block uses only keeps the
-        // workgroup's barrier count: four per (dz, pass)
+    if (TRZ * tz + cz > g.az) {
         for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
-        continue;
+        return;
     }
     issue_dma(0, pbuf_all[cz][0]);
 
@@ -605,29 +503,21 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         if (z == 3) {
             const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
             uint32_t* mine = cur + lane;
-            const uint32_t* up_w = cur + lane;                                      // own cells: the upper layer
-            // the lower layer: wave cz - 1's sums; for wave 0 the previous block's top layer
-            const uint32_t* lo_w = (cz > 0 ? pbuf_all[max(cz - 1, 0)][step & 1] : lower0) + lane;
-            uint32_t* cslot = carry + (size_t)((step >> 2) * 2) * CARRY_ROUND + lane;
-            // sum of this cell and its x-neighbour; cell sums are capped at 2^27 so that eight of
-            // them cannot wrap (a capped sum is far beyond any admissible distance)
-            auto pair_sum = [&](int e, int d) {
-                const uint32_t c = min((uint32_t)acc[e][d], 1u << 27);
-                const uint32_t right = (uint32_t)__builtin_amdgcn_update_dpp(
-                    0, (int)c, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
-                return c + right;
-            };
+            const uint32_t* lo_w = cur + lane;
+            const uint32_t* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;
 #pragma unroll
             for (int e0 = 0; e0 < NEP; e0 += NR0) {
 #pragma unroll
                 for (int e = e0; e < (e0 + NR0 < NEP ? e0 + NR0 : NEP); e++)
 #pragma unroll
-                    for (int d = 0; d < SWIN; d++) mine[64 * ((e - e0) * SWIN + d)] = pair_sum(e, d);
-                if (lower_carried && blk > 0 && !(march.flags & 1)) {
-#pragma unroll
-                    for (int k = 0; k < ((e0 + NR0 < NEP ? NR0 : NEP - e0)) * SWIN; k++)
-                        lower0[64 * k + lane] = cslot[(e0 ? CARRY_ROUND : 0) + 64 * k];
-                }
+                    for (int d = 0; d < SWIN; d++) {
+                        // cell sums are capped at 2^27 so that eight of them cannot wrap; a capped
+                        // sum is far beyond any admissible distance
+                        const uint32_t c = min((uint32_t)acc[e][d], 1u << 27);
+                        const uint32_t right = (uint32_t)__builtin_amdgcn_update_dpp(
+                            0, (int)c, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
+                        mine[64 * ((e - e0) * SWIN + d)] = c + right;
+                    }
                 __syncthreads();
                 if (ref_ok) {
                     // a dy row's block sums first (its 22 LDS reads in flight together), then its
@@ -640,7 +530,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 #pragma unroll
                         for (int d = 0; d < SWIN; d++) {
                             const uint32_t* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
-                            const uint32_t* c1 = up_w + 64 * ((e - e0) * SWIN + d);
+                            const uint32_t* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
                             Sv[0][d] = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]);
                         }
                         asm volatile("" ::: "memory");
@@ -667,15 +557,6 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
                     }
                 }
                 __syncthreads();
-                if (carries && !(march.flags & 2)) {
-                    // the top wave's sums are the next block's lowest layer (read there by wave 0 in
-                    // this same round, i.e. before this slot is written again)
-                    uint32_t* cw = cslot + (size_t)(e0 ? CARRY_ROUND : 0);
-#pragma unroll
-                    for (int e = e0; e < (e0 + NR0 < NEP ? e0 + NR0 : NEP); e++)
-#pragma unroll
-                        for (int d = 0; d < SWIN; d++) cw[64 * ((e - e0) * SWIN + d)] = pair_sum(e, d);
-                }
             }
 #pragma unroll
             for (int e = 0; e < NE; e++)
@@ -698,12 +579,6 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
             uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
             *reinterpret_cast<uint4*>(out + k) = v;
         }
-    }
-    }   // blocks of the segment
-
-    if (march.nblk > 1) {
-        __syncthreads();
-        if (threadIdx.x == 0) atomicExch(march.locks + slot_s, 0);
     }
 }
 
@@ -794,33 +669,11 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host launchers (called from exabm4d_api.cpp)
 // ------------------------------------------------------------------------------------------------
-size_t bm_carry_bytes() { return (size_t)CARRY_SLOTS * CARRY_SLOT * sizeof(uint32_t) + CARRY_SLOTS * sizeof(int); }
-
-// Blocks per segment of the march: as long as a segment is worth it and the launch still has a few
-// workgroups per CU to balance (a 256^3 volume has 81 (y, x) columns: it keeps the old tiling).
-static int march_blocks(const VolGeom& g, long long columns, const void* carry) {
-    if (!carry || g_bm_march <= 0) return 1;
-    if (g_bm_march > 1) return g_bm_march & 63;     // forced (tests, experiments)
-    for (int nblk = 8; nblk > 1; nblk /= 2) {
-        const int rseg = TCZ * nblk - 1;
-        const long long nseg = (g.az + rseg - 1) / rseg;
-        if (g.az >= TCZ * nblk / 2 && nseg * columns >= 2048) return nblk;
-    }
-    return 1;
-}
-int g_bm_march = 1;          // 0: old tiling; 1: automatic; n > 1: n blocks per segment
-
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
-                             const uint16_t* vol16, void* carry) {
+                             const uint16_t* vol16) {
     // vol16 != nullptr: the volume's uint16 counts XOR 0x8000 in guarded scratch; the caller has
     // checked that the integer kernel gives the float kernel's tables (keymax <= 2^24, nx even)
-    // carry: bm_carry_bytes() of device memory whose last CARRY_SLOTS ints are zero (the slot locks),
-    // or nullptr (old tiling)
-    March march;
-    march.flags = g_bm_march >> 6;
-    march.carry = static_cast<uint32_t*>(carry);
-    march.locks = carry ? reinterpret_cast<int*>(march.carry + (size_t)CARRY_SLOTS * CARRY_SLOT) : nullptr;
     if (!force_generic && vol16 && g.az > 0 && g.ay > 0 && g.ax > 0) {
         using Cube = TileShape16<8, 8>;
         using Flat = TileShape16<4, 16>;
@@ -829,15 +682,12 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         };
         const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
         const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
-        const int ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
-        march.nblk = march_blocks(g, (long long)ty * tx * batch, carry);
-        const int rseg = TCZ * march.nblk - 1;
-        const int tz = (g.az + rseg - 1) / rseg;
+        const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
         dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
         if (flat)
-            hipLaunchKernelGGL(bm_tile16_kernel<Flat>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx, march);
+            hipLaunchKernelGGL(bm_tile16_kernel<Flat>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx);
         else
-            hipLaunchKernelGGL(bm_tile16_kernel<Cube>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx, march);
+            hipLaunchKernelGGL(bm_tile16_kernel<Cube>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     } else if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
@@ -849,17 +699,14 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         // fewer (y, x) tiles = fewer idle cell lanes (64^3 patches: 5 flat tiles against 9 cubes)
         const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
         const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
-        const int ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
-        march.nblk = march_blocks(g, (long long)ty * tx * batch, carry);
-        const int rseg = TCZ * march.nblk - 1;
-        const int tz = (g.az + rseg - 1) / rseg;
+        const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
         dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
         if (flat)
             hipLaunchKernelGGL(bm_tile_kernel<Flat>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                               ty, tx, guarded, march);
+                               ty, tx, guarded);
         else
             hipLaunchKernelGGL(bm_tile_kernel<Cube>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                               ty, tx, guarded, march);
+                               ty, tx, guarded);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -43,7 +43,6 @@ struct exabm4d_ctx {
     int codec_version = 2;     // exabm4d_set_option("codec_version"): stream format the encoder writes
     int fuse_den_z = 1;        // exabm4d_set_option("fuse_den_z"): z pass of the denominator inside the normalisation
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
-    void* bm_carry = nullptr;  // block matching's march: carry slots + locks (bm_carry_bytes())
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
     std::string err;
@@ -168,24 +167,6 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     return EXABM4D_OK;
 }
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-// Block matching's march (bm_kernels.hip): per-workgroup carry slots, claimed through locks that must
-// read zero when a launch starts.  Allocated at the first use by a volume large enough to march; a
-// context without it (allocation failed) keeps the one-tile-per-workgroup launch.
-static void* bm_carry_of(exabm4d_ctx* ctx, const VolGeom& g, int batch) {
-    if (ctx->bm_carry) return ctx->bm_carry;
-    if (g_bm_march == 0 || g.az < 8) return nullptr;            // one block of cell layers: nothing to carry
-    void* p = nullptr;
-    if (hipMalloc(&p, bm_carry_bytes()) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    if (hipMemsetAsync(p, 0, bm_carry_bytes(), ctx->stream) != hipSuccess) {
-        (void)hipFree(p);
-        return nullptr;
-    }
-    ctx->bm_carry = p;
-    return p;
-}
 
 
 static int make_tfdev(exabm4d_ctx* ctx, const exabm4d_transform* t, TfDev& d) {
@@ -276,7 +257,6 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->bm_carry) (void)hipFree(ctx->bm_carry);
     if (ctx->red) (void)hipFree(ctx->red);
     if (ctx->rcp_dev) (void)hipFree(ctx->rcp_dev);
     if (ctx->codec_aux) (void)hipFree(ctx->codec_aux);
@@ -358,11 +338,6 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     }
     if (std::strcmp(name, "stage_pairvol") == 0) {      // Wiener gathers from an interleaved (noisy, basic) volume
         g_stage_pairvol = value ? 1 : 0;
-        return EXABM4D_OK;
-    }
-    if (std::strcmp(name, "bm_march") == 0) {           // block matching: 0 = one tile per workgroup, 1 = automatic, n = n blocks per segment
-        if (value < 0 || value > 255) return fail(ctx, EXABM4D_ERR_INVALID, "bm_march must be in [0, 63] (+ 64 / 128: timing probes)");
-        g_bm_march = value;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "stage_quads") == 0) {        // Wiener stage: four (1) or two (0) waves per group
@@ -497,11 +472,11 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
         HIP_TRY(ctx, hipMemcpyAsync(base + 256, vol, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, launch_blockmatch(reinterpret_cast<const float*>(base + 256), g, batch,
                                        keymax_of(sigma, c_match), keys, ctx->stream,
-                                       ctx->force_generic_bm, 1, nullptr, bm_carry_of(ctx, g, batch)));
+                                       ctx->force_generic_bm, 1));
         return EXABM4D_OK;
     }
     HIP_TRY(ctx, launch_blockmatch(vol, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm, 0, nullptr, bm_carry_of(ctx, g, batch)));
+                                   ctx->force_generic_bm, 0));
     return EXABM4D_OK;
 }
 
@@ -532,7 +507,7 @@ int exabm4d_blockmatch_u16_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, in
     if (!guarded_region_ok(ctx, f32, n * sizeof(float)))
         return fail(ctx, EXABM4D_ERR_INVALID, "internal: guarded volume without mapped slack around it");
     HIP_TRY(ctx, launch_blockmatch(f32, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr, bm_carry_of(ctx, g, batch)));
+                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr));
     return EXABM4D_OK;
 }
 
@@ -682,8 +657,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
                            offset_exact_in_fp32(u16_offset) &&
                            guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
         HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
-                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr,
-                                       bm_carry_of(ctx, g, batch)));
+                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
@@ -708,7 +682,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
             HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys,
-                                           s, ctx->force_generic_bm, 1, nullptr, bm_carry_of(ctx, g, batch)));
+                                           s, ctx->force_generic_bm, 1));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);

@@ -56,11 +56,9 @@ int ssim3d_partials(int nz, int ny, int nx);
 int ssim3d_max_window();
 hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny, int nx, int w,
                          double C1, double C2, double* partials, double* out1, hipStream_t s);
-size_t bm_carry_bytes();     // block matching's march: carry slots + slot locks (the locks, its last 2 KB, zeroed once)
-extern int g_bm_march;       // 0: one tile of eight cell layers per workgroup; 1: automatic; n > 1: n blocks per segment
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
-                             const uint16_t* vol16 = nullptr, void* carry = nullptr);
+                             const uint16_t* vol16 = nullptr);
 extern int g_stage_quads;    // Wiener stage: 1 = four waves per group (stage_quad_kernel), 0 = two (stage_half_kernel<true>)
 extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chunk count (0 = automatic)
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,

@@ -690,8 +690,6 @@ def main():
     ctx.set_option("profile", 1)
     if os.environ.get("EXABM4D_STAGE_CHUNKS"):           # diagnostic sweep (tools/dbg)
         ctx.set_option("stage_chunks", int(os.environ["EXABM4D_STAGE_CHUNKS"]))
-    if os.environ.get("EXABM4D_BM_MARCH"):               # A/B: block matching's march (0 = off, 1 = automatic, n = blocks)
-        ctx.set_option("bm_march", int(os.environ["EXABM4D_BM_MARCH"]))
     if os.environ.get("EXABM4D_STAGE_PAIRVOL"):          # A/B: Wiener gathers from the interleaved volume (1) or not (0)
         ctx.set_option("stage_pairvol", int(os.environ["EXABM4D_STAGE_PAIRVOL"]))
     if os.environ.get("EXABM4D_STAGE_QUADS"):            # A/B: Wiener stage on teams of 4 (1) or 2 (0) waves
