@@ -61,7 +61,7 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
-                                                      int tiles_x, int guarded) {
+                                                      int tiles_x, int guarded, int xcd_q) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS,
                   PCOLS = TS::PCOLS, PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) float pbuf_all[TCZ][2][PBUF];
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
 
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tile = xcd_q ? xcd_slab_sync(blockIdx.x, tiles_y * tiles_x, xcd_q) : xcd_contiguous(blockIdx.x, gridDim.x);
+    if (tile < 0) return;                          // padding of the slab-synchronous order
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -365,7 +366,7 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restrict__ vol_all, VolGeom g,
                                                         uint32_t keymax,
                                                         uint32_t* __restrict__ keys_all, int tiles_y,
-                                                        int tiles_x) {
+                                                        int tiles_x, int xcd_q) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS, PCOLS = TS::PCOLS,
                   PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) uint32_t pbuf_all[TCZ][2][PBUF];
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     const uint16_t* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
 
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tile = xcd_q ? xcd_slab_sync(blockIdx.x, tiles_y * tiles_x, xcd_q) : xcd_contiguous(blockIdx.x, gridDim.x);
+    if (tile < 0) return;                          // padding of the slab-synchronous order
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -669,6 +671,16 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host launchers (called from exabm4d_api.cpp)
 // ------------------------------------------------------------------------------------------------
+// Workgroup order: 0 = every XCD walks its own contiguous range of tiles (so the XCDs sit in different z
+// slabs of a large volume); 1 = all XCDs inside one slab of ty x tx tiles at a time (worth it once a slab
+// has a few tiles per CU).
+int g_bm_xcd_mode = 1;
+static int xcd_q_of(int tz, int ty, int tx) {
+    const long long per = (long long)ty * tx;
+    if (g_bm_xcd_mode == 0 || tz < 2 || per < 512) return 0;
+    return (int)((per + 7) / 8);
+}
+
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
                              const uint16_t* vol16) {
@@ -683,11 +695,12 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
         const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
         const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
-        dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
+        const int xq = xcd_q_of(tz, ty, tx);
+        dim3 grid((unsigned)(xq ? 8 * xq * tz : tz * ty * tx), (unsigned)batch);
         if (flat)
-            hipLaunchKernelGGL(bm_tile16_kernel<Flat>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx);
+            hipLaunchKernelGGL(bm_tile16_kernel<Flat>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx, xq);
         else
-            hipLaunchKernelGGL(bm_tile16_kernel<Cube>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx);
+            hipLaunchKernelGGL(bm_tile16_kernel<Cube>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx, xq);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     } else if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
@@ -700,13 +713,14 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
         const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
         const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
-        dim3 grid((unsigned)(tz * ty * tx), (unsigned)batch);
+        const int xq = xcd_q_of(tz, ty, tx);
+        dim3 grid((unsigned)(xq ? 8 * xq * tz : tz * ty * tx), (unsigned)batch);
         if (flat)
             hipLaunchKernelGGL(bm_tile_kernel<Flat>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                               ty, tx, guarded);
+                               ty, tx, guarded, xq);
         else
             hipLaunchKernelGGL(bm_tile_kernel<Cube>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                               ty, tx, guarded);
+                               ty, tx, guarded, xq);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

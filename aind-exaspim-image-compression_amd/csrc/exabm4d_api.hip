@@ -340,6 +340,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         g_stage_pairvol = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "bm_xcd_mode") == 0) {        // block matching's workgroup order (bm_kernels.hip)
+        g_bm_xcd_mode = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "stage_quads") == 0) {        // Wiener stage: four (1) or two (0) waves per group
         g_stage_quads = value ? 1 : 0;
         return EXABM4D_OK;

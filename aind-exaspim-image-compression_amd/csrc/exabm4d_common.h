@@ -83,4 +83,15 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nb) {
     return c * q + min(c, r) + i;
 }
 
+// The same idea with all eight XCDs inside ONE slab of `per` tiles at a time (tile index = slab * per +
+// position): XCD c walks positions [c q, (c + 1) q) of every slab, q = ceil(per / 8); positions >= per
+// are padding (returns -1).  Launch 8 q workgroups per slab.  The XCDs' working sets then lie in the
+// same planes, which the memory-side cache (256 MB) can hold once instead of eight times.
+__device__ __forceinline__ int xcd_slab_sync(int bid, int per, int q) {
+    const int c = bid & 7, j = bid >> 3;
+    const int slab = j / q, w = j - slab * q;
+    const int t = c * q + w;
+    return t < per ? slab * per + t : -1;
+}
+
 }  // namespace exabm4d

@@ -56,6 +56,7 @@ int ssim3d_partials(int nz, int ny, int nx);
 int ssim3d_max_window();
 hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny, int nx, int w,
                          double C1, double C2, double* partials, double* out1, hipStream_t s);
+extern int g_bm_xcd_mode;    // block matching's workgroup order: 0 = contiguous per XCD, 1 = all XCDs in one z slab of tiles
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
                              const uint16_t* vol16 = nullptr);

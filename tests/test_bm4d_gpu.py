@@ -518,3 +518,33 @@ def test_wiener_gathers_from_the_interleaved_volume(ctx, oracle):
     num_g, den_g = _stage_gpu(ctx, cn, kc, SIGMA, basic=cb)
     np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
     _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+
+
+def test_block_matching_workgroup_orders_give_identical_tables(ctx):
+    """bm_xcd_mode: 0 = every XCD walks its own contiguous range of tiles, 1 (default for large launches) =
+    all XCDs inside one z slab of tiles at a time, with padding workgroups that exit at once.  64 x 640 x 640:
+    3 slabs of 23 x 23 tiles, 5 padding positions per slab.  Same tables from both kernels."""
+    rng = np.random.default_rng(11)
+    vol = np.clip(rng.normal(37.0, SIGMA, (64, 640, 640)), 0, 65535).round().astype(np.uint16)
+    vol[20:40, 100:300, 200:420] += 500
+    f = vol.astype(np.float32) - np.float32(37.0)
+    g = [len(_native.grid_positions(n)) for n in vol.shape]
+    d_u16, d_f32 = ctx.to_device(vol), ctx.to_device(f)
+    d_keys = ctx.alloc(g[0] * g[1] * g[2] * 16 * 4)
+    got = {}
+    try:
+        for mode in (0, 1):
+            ctx.set_option("bm_xcd_mode", mode)
+            ctx.blockmatch_u16(d_u16, vol.shape, SIGMA, 3.0, d_keys)
+            ctx.sync()
+            a = d_keys.download((*g, 16), np.uint32)
+            ctx.blockmatch(d_f32, vol.shape, SIGMA, 0.6, d_keys)
+            ctx.sync()
+            got[mode] = (a, d_keys.download((*g, 16), np.uint32))
+    finally:
+        ctx.set_option("bm_xcd_mode", 1)
+        for b in (d_u16, d_f32, d_keys):
+            b.free()
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_array_equal(got[0][1], got[1][1])
+    assert (got[1][0][..., 0] & 0x7FF).max() == 0 and (got[1][0][..., 1] != 0xFFFFFFFF).mean() > 0.5   # self first, groups found
