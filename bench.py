@@ -519,6 +519,7 @@ def run_chunks(args, rank, local_rank, world, dist):
 
 
 _RESULT_FD = None
+RENDEZVOUS_NOTE = []          # non-empty when a multi-rank run could not use RCCL for its barrier (volumes mode only)
 
 
 def quiet_stdout():
@@ -632,9 +633,36 @@ def main():
             local_rank = 0
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
+            if os.environ.get("BENCH_REHEARSAL") == "2":     # tests: the RCCL rendezvous fails, on a one-GPU box
+                local_rank = 0
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            try:
+                import datetime
+                if os.environ.get("BENCH_REHEARSAL") == "2":
+                    raise RuntimeError("rehearsal: RCCL forced down")
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)                       # builds the RCCL communicator now, not inside the timed region
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as exc:                         # noqa: BLE001
+                # The default mode has no data-path collective (one independent volume per rank): the
+                # rendezvous only brackets the timed region.  If RCCL cannot come up on this node, the ranks
+                # meet over gloo instead (same barrier + MAX reduction on CPU tensors) and the line says so;
+                # the slab / chunk modes exchange device planes and fail loudly.
+                if args.mode != "volumes":
+                    raise
+                print(f"[bench] rank {rank}: RCCL rendezvous failed ({exc!r}); falling back to gloo for the barrier",
+                      file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:                            # noqa: BLE001
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                RENDEZVOUS_NOTE.append("gloo (RCCL did not come up: %s)" % type(exc).__name__)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     # (import order of torch and libexabm4d.so is free: _native.lib() settles which HIP runtime the
@@ -710,7 +738,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if rehearsal else f"cuda:{local_rank}")
+                         device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -809,6 +837,7 @@ def main():
                           f"lossless EXAC of the denoised volume in 64^3 chunks + config-5 leg "
                           f"(8^3 block DCT, q = {Q_STEP:g}, EXAC of the int32 indices)",
                 "sharding": "one independent volume per rank, no data-path collective",
+                **({"rendezvous": RENDEZVOUS_NOTE[0]} if RENDEZVOUS_NOTE else {}),
             },
             "roofline": roofline,
             "phase_ms": phase_avg,

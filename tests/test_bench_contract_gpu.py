@@ -94,6 +94,26 @@ def test_chunks_mode_takes_a_per_rank_shape():
 
 
 @pytest.mark.gpu
+def test_volumes_mode_survives_a_dead_rccl_rendezvous():
+    """The default mode has no data-path collective: when RCCL does not come up (BENCH_REHEARSAL=2 forces
+    that, both ranks on this box's one GPU) the ranks meet over gloo and the line says so; the slab mode,
+    which exchanges device planes, fails instead."""
+    env = dict(os.environ, BENCH_REHEARSAL="2")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "64", "--steps", "1",
+           "--warmup", "1", "--bm4dnet", "0", "--cpu-sample", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "gloo" in d["config"]["rendezvous"]
+    out = subprocess.run(cmd + ["--mode", "slabs"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0
+
+
+@pytest.mark.gpu
 def test_a_failing_rank_fails_the_launcher():
     env = dict(os.environ, BENCH_REHEARSAL="1", BENCH_FAIL_RANK="1")
     env.pop("WORLD_SIZE", None)
