@@ -25,7 +25,7 @@ struct __attribute__((packed, aligned(4))) float4u {
 };
 
 constexpr int TCZ = 8;       // cell layers per tile = waves per workgroup
-constexpr int TRZ = TCZ - 1; // reference layers per tile
+// (TCZ cell layers give TCZ - 1 reference layers -- or TCZ with the carry below)
 constexpr int NE = 6;        // dy values per pass (two passes: dy = -5..0 and 1..6, 6 is masked)
 constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
 // A wave is one z-layer of TCY x TCX cells (64 lanes).  8 x 8 is the shape for volumes; 4 x 16
@@ -42,10 +42,52 @@ struct TileShape {
     static constexpr int PSTR = TCX == 8 ? 56 : PCOLS;
     static constexpr int PCH = PSTR / 4;                    // 16-byte chunks per staged row
     static constexpr int NDMA = (PROWS * PCH + 63) / 64;    // LDS-DMA instructions per plane
-    // floats per plane buffer; also holds the cell-sum exchange: 33 sums x 64 cells
-    static constexpr int PBUF = NDMA * 256 > 2304 ? NDMA * 256 : 2304;
+    // floats per plane buffer: the staged rows (the tail of the last LDS-DMA instruction is masked off)
+    // or the cell-sum exchange, 33 sums x 64 cells + the y-neighbour overhang of the last row
+    static constexpr int PLANE = (PROWS * PSTR + 3) / 4 * 4;
+    static constexpr int PBUF = PLANE > 2144 ? PLANE : 2144;
     static_assert(TCY * TCX == 64 && PCOLS % 4 == 0 && PSTR % 4 == 0, "one wave per cell layer");
 };
+
+// CARRY (round 3).  A reference block is two cell layers, so a tile of eight cell layers gives seven
+// reference layers and every eighth layer is computed twice (as the top layer of a tile and as the
+// bottom layer of the next): 37 tiles for the 255 reference layers of a 1024^3 volume.  With the carry
+// a tile advances by EIGHT layers: wave w computes cell layer L = 8 tz + w and owns the reference layer
+// L - 1 -- its lower cells are wave w - 1's sums (LDS), and for wave 0 they are the sums wave 7 of the
+// tile BELOW formed, which travel through global memory: [2][columns][22 (dz, pass)][2 rounds][33 x 64],
+// a slot per column and tile parity.  Tiles run one per workgroup in slab order (xcd_slab_sync: all of
+// slab tz - 1 is dispatched before any of slab tz), so the producer of a tile's carry started a whole
+// slab earlier; `done[column]` (tiles finished) makes that a guarantee instead of a likelihood: waves 0
+// and 7 wait for done >= tz before they read / overwrite a slot, and a workgroup never waits for a
+// later one, so the wait cannot deadlock.  All carry traffic is system-scope (stores written through,
+// loads and the LDS-DMA prefetch with sc0 sc1): no assumption about which XCD's L2 a tile runs on.  Wave 0
+// fetches a (dz, pass)'s two rounds by LDS-DMA one plane ahead of their use: no registers, no wait in
+// front of the exchange barriers.  The same sums enter the same adds: tables are unchanged.
+constexpr int CARRY_ROUND = (NE / 2) * SWIN * 64;                 // elements of one exchange round (33 x 64)
+constexpr int CARRY_TILE = (NSTEP / 4) * 2 * CARRY_ROUND;         // one tile's top layer: 22 (dz, pass) x 2 rounds
+struct Carry {
+    int on;                  // 1: tiles advance by TCZ cell layers and carry their top layer
+    uint32_t* buf;           // [2][columns][CARRY_TILE]
+    int* done;               // [columns]: tiles of the column that have finished (zeroed per launch)
+};
+// Both rounds of one (dz, pass) into `dst` (2 * CARRY_ROUND elements, linear): 16 full 1 KB transfers
+// and one of 512 bytes.
+template <class T>
+__device__ __forceinline__ void carry_prefetch(const T* src, T* dst, int lane) {
+    static_assert(2 * CARRY_ROUND == 16 * 256 + 128, "two rounds = 16.5 KB");
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 256 * i + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 17);
+    if (lane < 32)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096 + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 17);
+}
+__device__ __forceinline__ void carry_wait_for(const int* done, int tiles, int lane) {
+    if (lane == 0)
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < tiles)
+            __builtin_amdgcn_s_sleep(32);
+}
 
 // Each WAVE (= one z-layer of 8x8 cells) streams the candidate planes it needs through its own
 // pair of LDS buffers: for a fixed dz and a pass of NE dy values, plane z+dz of the volume
@@ -61,10 +103,11 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
-                                                      int tiles_x, int guarded, int xcd_q) {
+                                                      int tiles_x, int guarded, int xcd_q, Carry carry) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS,
                   PCOLS = TS::PCOLS, PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) float pbuf_all[TCZ][2][PBUF];
+    __shared__ __align__(16) float lower0[2 * CARRY_ROUND + 64];   // wave 0's lower cell layer (from the carry), both rounds
 
     const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
@@ -74,16 +117,22 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int cx = lane % TCX, cy = lane / TCX, cz = tid >> 6;       // cz == wave index
-    const int ix = TRX * tx + cx, iy = TRY * ty + cy, iz = TRZ * tz + cz;  // cell == ref index
+    const int cx = lane % TCX, cy = lane / TCX, cz = __builtin_amdgcn_readfirstlane(tid >> 6);   // cz == wave index
+    const int ix = TRX * tx + cx, iy = TRY * ty + cy;                 // cell == ref index in y, x
 
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
+    // cell layers a tile advances by (CARRY above); this tile's column and its two carry slots
+    const int Ls = (carry.on ? TCZ : TCZ - 1) * tz;
+    constexpr int nb = 1;
+    const int pos = ty * tiles_x + tx, per = tiles_y * tiles_x;
+    const float* carry_rd = reinterpret_cast<const float*>(carry.buf) + ((size_t)((tz + 1) & 1) * per + pos) * CARRY_TILE;
+    float* carry_wr = reinterpret_cast<float*>(carry.buf) + ((size_t)(tz & 1) * per + pos) * CARRY_TILE;
+
     // Cell origin; cells beyond the volume are clamped inside it (their sums are never used).
-    const int qz = min(STEP * iz, g.nz - STEP), qy = min(STEP * iy, g.ny - STEP),
-              qx = min(STEP * ix, g.nx - STEP);
+    const int qy = min(STEP * iy, g.ny - STEP), qx = min(STEP * ix, g.nx - STEP);
     // Tile origin (voxels) of the staged window; wave-uniform.
-    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD, Z0 = STEP * (TRZ * tz + cz);
+    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD;
     // Whole staged column range inside the volume?  (wave-uniform; edge tiles clamp per element.)
     // `guarded`: the volume is one of the library's own buffers, with >= 256 bytes of mapped memory
     // on either side.  Columns outside the volume then need no clamping at all: they only ever
@@ -92,18 +141,33 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // LDS-DMA path too and read whatever lies beyond the row ends.
     const bool xin = guarded || ((X0 >= 0) && (X0 + PCOLS - 1 <= g.nx - 1));
 
-    const bool ref_ok = cx < TRX && cy < TRY && cz < TRZ && iz < g.az && iy < g.ay && ix < g.ax;
-    const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
+    const bool ref_yx = cx < TRX && cy < TRY && iy < g.ay && ix < g.ax;
+    const int ry = STEP * iy, rx = STEP * ix;
 
-    uint32_t list[MAXG];
-#pragma unroll
-    for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
-    uint32_t thr = keymax;       // min(list[15], keymax): a key below it enters the list
     // bit d set iff candidate displacement dx = d - 5 keeps the block inside the volume
     uint32_t xmask = 0;
 #pragma unroll
     for (int d = 0; d < SWIN; d++)
         xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
+
+    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
+#pragma unroll 1
+    for (int blk = 0; blk < nb; blk++) {
+    const int L = Ls + cz;                             // this wave's cell layer
+    const bool active = L <= g.az;
+    const int iz = L - 1;                              // the reference layer it owns (lower cells: wave cz - 1)
+    const int qz = min(STEP * L, g.nz - STEP);
+    const int Z0 = STEP * L;
+    const bool lower_carried = carry.on && cz == 0 && tz > 0;          // the lower layer is the tile below's top layer
+    const bool carries = carry.on && cz == TCZ - 1 && L + 1 <= g.az;   // ... and this wave's sums are the next tile's
+    const bool ref_ok = ref_yx && active && (cz > 0 || lower_carried);
+    if ((lower_carried || carries) && tz > 0) carry_wait_for(carry.done + pos, tz, lane);
+    const int rz = STEP * iz;
+
+    uint32_t list[MAXG];
+#pragma unroll
+    for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
+    uint32_t thr = keymax;       // min(list[15], keymax): a key below it enters the list
 
     auto step_plane = [&](int step, int& dylo) -> const float* {
         const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
@@ -118,7 +182,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // the row of a chunk needs no clamp, so its source is a wave-uniform base (plane, first row,
     // first column) plus a lane constant r * sy + 4 q -- eight instructions per DMA instead of the
     // thirty of the clamped form (a fifth of a step's instructions went into these addresses).
-    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
     auto issue_dma = [&](int step, float* dst) {
         int dylo;
         const float* plane = step_plane(step, dylo);
@@ -133,9 +196,10 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                 const unsigned r = min(r0, (unsigned)(PROWS - 1));
                 const unsigned q = min(p - r0 * PCH, (unsigned)(PCOLS / 4 - 1));
                 const float* src = base + (r * (unsigned)sy + 4u * q);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)src,
-                    (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
+                if (64 * i + 64 <= PROWS * PCH || p < (unsigned)(PROWS * PCH))       // chunks past the last row stay unwritten
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)src,
+                        (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
             }
             return;
         }
@@ -145,9 +209,10 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             const int r = min(p / PCH, PROWS - 1), q = min(p % PCH, PCOLS / 4 - 1);
             const int yy = min(max(Y0 + dylo + r, 0), g.ny - 1);
             const float* src = plane + (size_t)yy * sy + (X0 + 4 * q);
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)src,
-                (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
+            if (64 * i + 64 <= PROWS * PCH || p < PROWS * PCH)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)src,
+                    (__attribute__((address_space(3))) void*)(dst + 256 * i), 16, 0, 0);
         }
     };
     auto stage_edge = [&](int step, float* dst) {               // edge tiles: clamp per element
@@ -164,9 +229,9 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // A wave whose cell layer lies beyond the last one any reference block uses (layers 0 .. az)
     // has nothing to contribute -- the last z tile of a 64^3 patch needs 2 of its 8 layers -- and
     // only keeps the workgroup's barrier count: four per (dz, pass).
-    if (TRZ * tz + cz > g.az) {
+    if (!active) {
         for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
-        return;
+        continue;
     }
 
     if (xin)
@@ -205,6 +270,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
         // (conditional) DMA block, which would expose the whole DMA latency every step.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (xin && step + 1 < NSTEP) issue_dma(step + 1, nxt);
+        if (lower_carried && z == 2) carry_prefetch(carry_rd + (size_t)(step >> 2) * 2 * CARRY_ROUND, lower0, lane);
 
         // ---- accumulate: row rp = y + e of the cell's window -----------------------------------
         {
@@ -251,8 +317,10 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             // exchange slot of cell (wave w, local l), displacement d: pbuf_all[w][cur][64 d + l]
             const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
             float* mine = cur + lane;
-            const float* lo_w = cur + lane;                                  // cells of wave cz
-            const float* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;  // wave cz + 1
+            const float* up_w = cur + lane;                                  // own cells: the upper layer
+            // the lower layer: wave cz - 1's sums; for wave 0 the previous block's top layer
+            const float* lo_w = (cz > 0 ? pbuf_all[max(cz - 1, 0)][step & 1] : lower0) + lane;
+            float* cslot = carry_wr + (size_t)((step >> 2) * 2) * CARRY_ROUND + lane;
             // NE / 2 dy values per round (33 sums per cell fit the 36 slots of a plane buffer):
             // two barrier pairs per pass instead of six.  Each cell lane first adds its
             // x-neighbour's sum (DPP row_shl:1, no LDS), so a reference lane reads 4 values per
@@ -279,8 +347,8 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                             const bool self_row = (dz == 0) && (dy == 0);
 #pragma unroll
                             for (int d = 0; d < SWIN; d++) {
-                                const float* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
-                                const float* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
+                                const float* c0 = lo_w + (cz == 0 && e0 ? CARRY_ROUND : 0) + 64 * ((e - e0) * SWIN + d);
+                                const float* c1 = up_w + 64 * ((e - e0) * SWIN + d);
                                 // S = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]) as three plain adds: left
                                 // to the SLP vectoriser this becomes two packed adds, three moves and
                                 // two wait states
@@ -303,6 +371,19 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
                     }
                 }
                 __syncthreads();
+                if (carries) {
+                    // the top wave's sums are the next block's lowest layer (read there by wave 0 in
+                    // this same round, i.e. before this slot is written again)
+#pragma unroll
+                    for (int e = e0; e < e0 + NE / 2; e++)
+#pragma unroll
+                        for (int d = 0; d < SWIN; d++) {
+                            const float right = __int_as_float(__builtin_amdgcn_update_dpp(
+                                0, __float_as_int(acc[e][d]), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+                            __hip_atomic_store(cslot + (e0 ? CARRY_ROUND : 0) + 64 * ((e - e0) * SWIN + d), acc[e][d] + right,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                }
             }
 #pragma unroll
             for (int e = 0; e < NE; e++)
@@ -321,6 +402,14 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
             *reinterpret_cast<uint4*>(out + k) = v;
         }
+    }
+    }   // blocks of the segment
+
+    if (carry.on) {
+        // the tile is finished when wave 7's stores have been acknowledged and wave 0's last prefetch has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(carry.done + pos, tz + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -366,10 +455,11 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restrict__ vol_all, VolGeom g,
                                                         uint32_t keymax,
                                                         uint32_t* __restrict__ keys_all, int tiles_y,
-                                                        int tiles_x, int xcd_q) {
+                                                        int tiles_x, int xcd_q, Carry carry) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS, PCOLS = TS::PCOLS,
                   PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) uint32_t pbuf_all[TCZ][2][PBUF];
+    __shared__ __align__(16) uint32_t lower0[2 * CARRY_ROUND + 64];   // wave 0's lower cell layer (from the carry), both rounds
 
     const uint16_t* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
     uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
@@ -379,30 +469,49 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int cx = lane % TCX, cy = lane / TCX, cz = tid >> 6;
-    const int ix = TRX * tx + cx, iy = TRY * ty + cy, iz = TRZ * tz + cz;
+    const int cx = lane % TCX, cy = lane / TCX, cz = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ix = TRX * tx + cx, iy = TRY * ty + cy;
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
-    const int qz = min(STEP * iz, g.nz - STEP), qy = min(STEP * iy, g.ny - STEP),
-              qx = min(STEP * ix, g.nx - STEP);
+    // cell layers a tile advances by (CARRY above); this tile's column and its two carry slots
+    const int Ls = (carry.on ? TCZ : TCZ - 1) * tz;
+    constexpr int nb = 1;
+    const int pos = ty * tiles_x + tx, per = tiles_y * tiles_x;
+    const uint32_t* carry_rd = carry.buf + ((size_t)((tz + 1) & 1) * per + pos) * CARRY_TILE;
+    uint32_t* carry_wr = carry.buf + ((size_t)(tz & 1) * per + pos) * CARRY_TILE;
+
+    const int qy = min(STEP * iy, g.ny - STEP), qx = min(STEP * ix, g.nx - STEP);
     // staged window: rows Y0 + dylo ..., columns X0 ... with X0 even (one column more to the left
     // than the search needs): cell cx finds candidate column x + d of its voxel x at staged
     // column 4 cx + 1 + x + d
-    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD - 1, Z0 = STEP * (TRZ * tz + cz);
+    const int Y0 = STEP * TRY * ty, X0 = STEP * TRX * tx - RAD - 1;
+    const int ry = STEP * iy, rx = STEP * ix;
+    const bool ref_yx = cx < TRX && cy < TRY && iy < g.ay && ix < g.ax;
 
-    const bool ref_ok = cx < TRX && cy < TRY && cz < TRZ && iz < g.az && iy < g.ay && ix < g.ax;
-    const int rz = STEP * iz, ry = STEP * iy, rx = STEP * ix;
+    uint32_t xmask = 0;
+#pragma unroll
+    for (int d = 0; d < SWIN; d++)
+        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
+    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
+
+#pragma unroll 1
+    for (int blk = 0; blk < nb; blk++) {
+    const int L = Ls + cz;                             // this wave's cell layer
+    const bool active = L <= g.az;                     // cell layers 0 .. az exist
+    const int iz = L - 1;                              // ... and the reference layer it owns
+    const int qz = min(STEP * L, g.nz - STEP);
+    const int Z0 = STEP * L;
+    const bool lower_carried = carry.on && cz == 0 && tz > 0;          // the lower layer is the tile below's top layer
+    const bool carries = carry.on && cz == TCZ - 1 && L + 1 <= g.az;   // ... and this wave's sums are the next tile's
+    const bool ref_ok = ref_yx && active && (cz > 0 || lower_carried);
+    if ((lower_carried || carries) && tz > 0) carry_wait_for(carry.done + pos, tz, lane);
+    const int rz = STEP * iz;
 
     uint32_t list[MAXG];
 #pragma unroll
     for (int k = 0; k < MAXG; k++) list[k] = KEY_EMPTY;
     uint32_t thr = keymax;
-    uint32_t xmask = 0;
-#pragma unroll
-    for (int d = 0; d < SWIN; d++)
-        xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
 
-    const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
     auto issue_dma = [&](int step, uint32_t* dst) {
         const int z = step & 3, pass = (step >> 2) & 1, dz = (step >> 3) - RAD;
         const int dylo = pass == 0 ? -RAD : 1;
@@ -424,9 +533,11 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         }
     };
 
-    if (TRZ * tz + cz > g.az) {
+    if (!active) {
+        // a wave whose cell layer lies beyond the last one any reference block uses only keeps the
+        // workgroup's barrier count: four per (dz, pass)
         for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
-        return;
+        continue;
     }
     issue_dma(0, pbuf_all[cz][0]);
 
@@ -460,6 +571,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (step + 1 < NSTEP) issue_dma(step + 1, nxt);
+        if (lower_carried && z == 2) carry_prefetch(carry_rd + (size_t)(step >> 2) * 2 * CARRY_ROUND, lower0, lane);
 
         {
             const uint32_t* wrow = cur + ((4 * cy) * PSTR + 4 * cx) / 2;       // dword index
@@ -505,21 +617,24 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         if (z == 3) {
             const bool vz = (rz + dz >= 0) && (rz + dz <= g.nz - BLK);
             uint32_t* mine = cur + lane;
-            const uint32_t* lo_w = cur + lane;
-            const uint32_t* hi_w = pbuf_all[min(cz + 1, TCZ - 1)][step & 1] + lane;
+            const uint32_t* up_w = cur + lane;                                      // own cells: the upper layer
+            // the lower layer: wave cz - 1's sums; for wave 0 the previous block's top layer
+            const uint32_t* lo_w = (cz > 0 ? pbuf_all[max(cz - 1, 0)][step & 1] : lower0) + lane;
+            uint32_t* cslot = carry_wr + (size_t)((step >> 2) * 2) * CARRY_ROUND + lane;
+            // sum of this cell and its x-neighbour; cell sums are capped at 2^27 so that eight of
+            // them cannot wrap (a capped sum is far beyond any admissible distance)
+            auto pair_sum = [&](int e, int d) {
+                const uint32_t c = min((uint32_t)acc[e][d], 1u << 27);
+                const uint32_t right = (uint32_t)__builtin_amdgcn_update_dpp(
+                    0, (int)c, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
+                return c + right;
+            };
 #pragma unroll
             for (int e0 = 0; e0 < NEP; e0 += NR0) {
 #pragma unroll
                 for (int e = e0; e < (e0 + NR0 < NEP ? e0 + NR0 : NEP); e++)
 #pragma unroll
-                    for (int d = 0; d < SWIN; d++) {
-                        // cell sums are capped at 2^27 so that eight of them cannot wrap; a capped
-                        // sum is far beyond any admissible distance
-                        const uint32_t c = min((uint32_t)acc[e][d], 1u << 27);
-                        const uint32_t right = (uint32_t)__builtin_amdgcn_update_dpp(
-                            0, (int)c, 0x101 /* row_shl:1 */, 0xF, 0xF, true);
-                        mine[64 * ((e - e0) * SWIN + d)] = c + right;
-                    }
+                    for (int d = 0; d < SWIN; d++) mine[64 * ((e - e0) * SWIN + d)] = pair_sum(e, d);
                 __syncthreads();
                 if (ref_ok) {
                     // a dy row's block sums first (its 22 LDS reads in flight together), then its
@@ -531,8 +646,8 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
                         uint32_t Sv[1][SWIN];          // one dy row of sums at a time (registers)
 #pragma unroll
                         for (int d = 0; d < SWIN; d++) {
-                            const uint32_t* c0 = lo_w + 64 * ((e - e0) * SWIN + d);
-                            const uint32_t* c1 = hi_w + 64 * ((e - e0) * SWIN + d);
+                            const uint32_t* c0 = lo_w + (cz == 0 && e0 ? CARRY_ROUND : 0) + 64 * ((e - e0) * SWIN + d);
+                            const uint32_t* c1 = up_w + 64 * ((e - e0) * SWIN + d);
                             Sv[0][d] = (c0[0] + c0[TCX]) + (c1[0] + c1[TCX]);
                         }
                         asm volatile("" ::: "memory");
@@ -559,6 +674,17 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
                     }
                 }
                 __syncthreads();
+                if (carries) {
+                    // the top wave's sums are the next block's lowest layer (read there by wave 0 in
+                    // this same round, i.e. before this slot is written again)
+                    uint32_t* cw = cslot + (size_t)(e0 ? CARRY_ROUND : 0);
+#pragma unroll
+                    for (int e = e0; e < (e0 + NR0 < NEP ? e0 + NR0 : NEP); e++)
+#pragma unroll
+                        for (int d = 0; d < SWIN; d++)
+                            __hip_atomic_store(cw + 64 * ((e - e0) * SWIN + d), pair_sum(e, d), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
 #pragma unroll
             for (int e = 0; e < NE; e++)
@@ -581,6 +707,14 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
             uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
             *reinterpret_cast<uint4*>(out + k) = v;
         }
+    }
+    }   // blocks of the segment
+
+    if (carry.on) {
+        // the tile is finished when wave 7's stores have been acknowledged and wave 0's last prefetch has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(carry.done + pos, tz + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -675,52 +809,83 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // slabs of a large volume); 1 = all XCDs inside one slab of ty x tx tiles at a time (worth it once a slab
 // has a few tiles per CU).
 int g_bm_xcd_mode = 1;
-static int xcd_q_of(int tz, int ty, int tx) {
-    const long long per = (long long)ty * tx;
-    if (g_bm_xcd_mode == 0 || tz < 2 || per < 512) return 0;
-    return (int)((per + 7) / 8);
+// Carry between the tiles of a column (CARRY above): 0 = off (tiles advance by seven cell layers), 1 = on
+// where the launch runs in slab order, 2 = slab order and carry forced (tests: small volumes).
+int g_bm_carry = 1;
+
+struct TilePlan {
+    int ty, tx, tz, xq, carry;
+};
+static TilePlan plan_tiles(const VolGeom& g, int batch, int try_, int trx, bool have_carry) {
+    TilePlan p;
+    p.ty = (g.ay + try_ - 1) / try_;
+    p.tx = (g.ax + trx - 1) / trx;
+    const long long per = (long long)p.ty * p.tx;
+    const int tz7 = (g.az + TCZ - 2) / (TCZ - 1), tz8 = g.az / TCZ + 1;
+    const bool slab = g_bm_xcd_mode != 0 && per >= 512;
+    p.carry = (have_carry && batch == 1 && g_bm_carry != 0 && ((slab && tz8 >= 2) || g_bm_carry == 2)) ? 1 : 0;
+    p.tz = p.carry ? tz8 : tz7;
+    p.xq = (p.carry || (slab && p.tz >= 2)) ? (int)((per + 7) / 8) : 0;
+    return p;
+}
+// Tile shape: fewer (y, x) tiles = fewer idle cell lanes (64^3 patches: 5 flat tiles against 9 cubes)
+template <class Cube, class Flat>
+static bool flat_tiles(const VolGeom& g) {
+    auto tiles = [&](int try_, int trx) {
+        return (long long)((g.ay + try_ - 1) / try_) * ((g.ax + trx - 1) / trx);
+    };
+    return tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
+}
+size_t bm_carry_bytes(const VolGeom& g, int batch) {
+    if (g.az <= 0 || g.ay <= 0 || g.ax <= 0) return 0;
+    // the same decision the launcher takes (the float and the integer kernel share tile shapes)
+    const bool flat = flat_tiles<TileShape<8, 8>, TileShape<4, 16>>(g);
+    const TilePlan p = plan_tiles(g, batch, flat ? 3 : 7, flat ? 15 : 7, true);
+    if (!p.carry) return 0;
+    const size_t per = (size_t)p.ty * p.tx;
+    return 2 * per * CARRY_TILE * sizeof(uint32_t) + per * sizeof(int);
 }
 
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
-                             const uint16_t* vol16) {
+                             const uint16_t* vol16, void* carry_mem) {
     // vol16 != nullptr: the volume's uint16 counts XOR 0x8000 in guarded scratch; the caller has
     // checked that the integer kernel gives the float kernel's tables (keymax <= 2^24, nx even)
-    if (!force_generic && vol16 && g.az > 0 && g.ay > 0 && g.ax > 0) {
-        using Cube = TileShape16<8, 8>;
-        using Flat = TileShape16<4, 16>;
-        auto tiles = [&](int try_, int trx) {
-            return (long long)((g.ay + try_ - 1) / try_) * ((g.ax + trx - 1) / trx);
-        };
-        const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
-        const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
-        const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
-        const int xq = xcd_q_of(tz, ty, tx);
-        dim3 grid((unsigned)(xq ? 8 * xq * tz : tz * ty * tx), (unsigned)batch);
-        if (flat)
-            hipLaunchKernelGGL(bm_tile16_kernel<Flat>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx, xq);
-        else
-            hipLaunchKernelGGL(bm_tile16_kernel<Cube>, grid, dim3(512), 0, stream, vol16, g, keymax, keys, ty, tx, xq);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    } else if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
+    // carry_mem: bm_carry_bytes(g, batch) of device memory, or nullptr (tiles advance by seven layers)
+    if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
+        const bool flat = flat_tiles<TileShape<8, 8>, TileShape<4, 16>>(g);
+        static_assert(TileShape<8, 8>::TRY == TileShape16<8, 8>::TRY && TileShape<4, 16>::TRX == TileShape16<4, 16>::TRX,
+                      "one tile plan for both kernels");
+        const TilePlan p = plan_tiles(g, batch, flat ? 3 : 7, flat ? 15 : 7, carry_mem != nullptr);
+        Carry carry;
+        carry.on = p.carry;
+        carry.buf = static_cast<uint32_t*>(carry_mem);
+        const size_t per = (size_t)p.ty * p.tx;
+        carry.done = p.carry ? reinterpret_cast<int*>(carry.buf + 2 * per * CARRY_TILE) : nullptr;
+        if (p.carry) {
+            hipError_t e = hipMemsetAsync(carry.done, 0, per * sizeof(int), stream);
+            if (e != hipSuccess) return e;
+        }
+        dim3 grid((unsigned)(p.xq ? 8 * p.xq * p.tz : p.tz * p.ty * p.tx), (unsigned)batch);
+        using Cube16 = TileShape16<8, 8>;
+        using Flat16 = TileShape16<4, 16>;
         using Cube = TileShape<8, 8>;
         using Flat = TileShape<4, 16>;
-        auto tiles = [&](int try_, int trx) {
-            return (long long)((g.ay + try_ - 1) / try_) * ((g.ax + trx - 1) / trx);
-        };
-        // fewer (y, x) tiles = fewer idle cell lanes (64^3 patches: 5 flat tiles against 9 cubes)
-        const bool flat = tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
-        const int try_ = flat ? Flat::TRY : Cube::TRY, trx = flat ? Flat::TRX : Cube::TRX;
-        const int tz = (g.az + TRZ - 1) / TRZ, ty = (g.ay + try_ - 1) / try_, tx = (g.ax + trx - 1) / trx;
-        const int xq = xcd_q_of(tz, ty, tx);
-        dim3 grid((unsigned)(xq ? 8 * xq * tz : tz * ty * tx), (unsigned)batch);
-        if (flat)
-            hipLaunchKernelGGL(bm_tile_kernel<Flat>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                               ty, tx, guarded, xq);
-        else
-            hipLaunchKernelGGL(bm_tile_kernel<Cube>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                               ty, tx, guarded, xq);
+        if (vol16) {
+            if (flat)
+                hipLaunchKernelGGL(bm_tile16_kernel<Flat16>, grid, dim3(512), 0, stream, vol16, g, keymax,
+                                   keys, p.ty, p.tx, p.xq, carry);
+            else
+                hipLaunchKernelGGL(bm_tile16_kernel<Cube16>, grid, dim3(512), 0, stream, vol16, g, keymax,
+                                   keys, p.ty, p.tx, p.xq, carry);
+        } else {
+            if (flat)
+                hipLaunchKernelGGL(bm_tile_kernel<Flat>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
+                                   p.ty, p.tx, guarded, p.xq, carry);
+            else
+                hipLaunchKernelGGL(bm_tile_kernel<Cube>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
+                                   p.ty, p.tx, guarded, p.xq, carry);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -43,6 +43,8 @@ struct exabm4d_ctx {
     int codec_version = 2;     // exabm4d_set_option("codec_version"): stream format the encoder writes
     int fuse_den_z = 1;        // exabm4d_set_option("fuse_den_z"): z pass of the denominator inside the normalisation
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
+    void* bm_carry = nullptr;  // block matching: the tiles' carried cell layers (bm_carry_bytes())
+    size_t bm_carry_size = 0;
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
     std::string err;
@@ -167,6 +169,25 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     return EXABM4D_OK;
 }
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+// Block matching's carry between the tiles of a column (bm_kernels.hip, CARRY): 372 KB per column and tile
+// parity, 1 GB at 1024^3.  A context that cannot get it keeps the launch without the carry.
+static void* bm_carry_of(exabm4d_ctx* ctx, const VolGeom& g, int batch) {
+    const size_t need = bm_carry_bytes(g, batch);
+    if (need == 0) return nullptr;
+    if (need <= ctx->bm_carry_size) return ctx->bm_carry;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+    if (ctx->bm_carry) (void)hipFree(ctx->bm_carry);
+    ctx->bm_carry = nullptr;
+    ctx->bm_carry_size = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->bm_carry = p;
+    ctx->bm_carry_size = need;
+    return p;
+}
 
 
 static int make_tfdev(exabm4d_ctx* ctx, const exabm4d_transform* t, TfDev& d) {
@@ -257,6 +278,7 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->bm_carry) (void)hipFree(ctx->bm_carry);
     if (ctx->red) (void)hipFree(ctx->red);
     if (ctx->rcp_dev) (void)hipFree(ctx->rcp_dev);
     if (ctx->codec_aux) (void)hipFree(ctx->codec_aux);
@@ -338,6 +360,11 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     }
     if (std::strcmp(name, "stage_pairvol") == 0) {      // Wiener gathers from an interleaved (noisy, basic) volume
         g_stage_pairvol = value ? 1 : 0;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "bm_carry") == 0) {           // block matching: carry between the tiles of a column (0 off, 1 automatic, 2 forced)
+        if (value < 0 || value > 2) return fail(ctx, EXABM4D_ERR_INVALID, "bm_carry must be 0, 1 or 2");
+        g_bm_carry = value;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "bm_xcd_mode") == 0) {        // block matching's workgroup order (bm_kernels.hip)
@@ -476,11 +503,11 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
         HIP_TRY(ctx, hipMemcpyAsync(base + 256, vol, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, launch_blockmatch(reinterpret_cast<const float*>(base + 256), g, batch,
                                        keymax_of(sigma, c_match), keys, ctx->stream,
-                                       ctx->force_generic_bm, 1));
+                                       ctx->force_generic_bm, 1, nullptr, bm_carry_of(ctx, g, batch)));
         return EXABM4D_OK;
     }
     HIP_TRY(ctx, launch_blockmatch(vol, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm, 0));
+                                   ctx->force_generic_bm, 0, nullptr, bm_carry_of(ctx, g, batch)));
     return EXABM4D_OK;
 }
 
@@ -511,7 +538,7 @@ int exabm4d_blockmatch_u16_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, in
     if (!guarded_region_ok(ctx, f32, n * sizeof(float)))
         return fail(ctx, EXABM4D_ERR_INVALID, "internal: guarded volume without mapped slack around it");
     HIP_TRY(ctx, launch_blockmatch(f32, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr));
+                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr, bm_carry_of(ctx, g, batch)));
     return EXABM4D_OK;
 }
 
@@ -661,7 +688,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
                            offset_exact_in_fp32(u16_offset) &&
                            guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
         HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
-                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr));
+                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr,
+                                       bm_carry_of(ctx, g, batch)));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
@@ -686,7 +714,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
             HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys,
-                                           s, ctx->force_generic_bm, 1));
+                                           s, ctx->force_generic_bm, 1, nullptr, bm_carry_of(ctx, g, batch)));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);

@@ -1,0 +1,103 @@
+"""Block matching's carry between the tiles of a column (bm_kernels.hip, round 3): a tile advances by eight
+cell layers instead of seven and takes the lower cells of its first reference layer from the tile below,
+through global memory, in slab order behind a per-column counter.  The same sums enter the same adds:
+tables must be bit-identical to the launch without the carry and to the oracle -- ragged last tiles, idle
+waves, both tile shapes, the float and the integer kernel, batches (which keep the old tiling)."""
+import numpy as np
+import pytest
+
+from util import synth_volume
+
+from aind_exaspim_image_compression import _native
+
+pytestmark = pytest.mark.gpu
+SIGMA = 24.0
+
+
+def _keys(ctx, vol, c_match, integer, batch=1):
+    shape = vol.shape[-3:]
+    g = [len(_native.grid_positions(n)) for n in shape]
+    src = vol if integer else (vol.astype(np.float32) - np.float32(37.0))
+    d_vol = ctx.to_device(np.ascontiguousarray(src))
+    d_keys = ctx.alloc(batch * g[0] * g[1] * g[2] * 16 * 4)
+    try:
+        if integer:
+            ctx.blockmatch_u16(d_vol, shape, SIGMA, c_match, d_keys, batch=batch)
+        else:
+            ctx.blockmatch(d_vol, shape, SIGMA, c_match, d_keys, batch=batch)
+        ctx.sync()
+        return d_keys.download((batch, *g, 16) if batch > 1 else (*g, 16), np.uint32)
+    finally:
+        d_vol.free()
+        d_keys.free()
+
+
+@pytest.fixture
+def carry(ctx):
+    def set_carry(n):
+        ctx.set_option("bm_carry", n)      # 0 off, 1 automatic (large launches), 2 forced
+    yield set_carry
+    ctx.set_option("bm_carry", 1)
+
+
+@pytest.mark.parametrize("integer", [False, True])
+@pytest.mark.parametrize("shape", [(100, 40, 44), (72, 36, 68), (134, 24, 32)])
+def test_carried_tables_equal_tiled_tables_and_the_oracle(ctx, oracle, carry, shape, integer):
+    """24 / 17 / 32 reference layers = 4 / 3 / 5 tiles of eight cell layers in a column, the last one with
+    idle waves (1 / 2 / 1 cell layers in use); few tiles per slab, so most slab positions of an XCD are padding."""
+    vol = synth_volume(shape, seed=sum(shape), as_u16=True)[0]
+    carry(0)
+    tiled = _keys(ctx, vol, 3.0, integer)
+    if integer:
+        f = vol.astype(np.float32)           # blockmatch_u16 matches on the counts themselves (offset 0)
+    else:
+        f = vol.astype(np.float32) - np.float32(37.0)
+    np.testing.assert_array_equal(tiled, oracle.blockmatch(f, SIGMA, 3.0))
+    carry(2)
+    for rep in range(3):          # the slots of a column are reused by every second tile and by every launch
+        np.testing.assert_array_equal(_keys(ctx, vol, 3.0, integer), tiled, err_msg=f"launch {rep}")
+    np.testing.assert_array_equal(_keys(ctx, vol, 0.6, integer), oracle.blockmatch(f, SIGMA, 0.6))
+
+
+@pytest.mark.parametrize("integer", [False, True])
+def test_carry_with_patches_batches_and_unaligned_planes(ctx, oracle, carry, integer):
+    """A 64^3 patch takes the 4 x 16 tile shape (15 reference layers = two tiles with the carry); a batch
+    keeps the tiling without it, whatever the option says; a 102-plane volume has a clamped last grid
+    position (generic kernel) next to its carried layers."""
+    vols = np.stack([synth_volume((64, 64, 64), seed=70 + i, as_u16=True)[0] for i in range(3)])
+    carry(2)
+    f0 = vols[0].astype(np.float32) - (np.float32(0.0) if integer else np.float32(37.0))
+    np.testing.assert_array_equal(_keys(ctx, vols[0], 3.0, integer), oracle.blockmatch(f0, SIGMA, 3.0))
+    got = _keys(ctx, vols, 3.0, integer, batch=3)
+    for i in range(3):
+        f = vols[i].astype(np.float32) - (np.float32(0.0) if integer else np.float32(37.0))
+        np.testing.assert_array_equal(got[i], oracle.blockmatch(f, SIGMA, 3.0))
+    vol = synth_volume((102, 32, 40), seed=9, as_u16=True)[0]
+    f = vol.astype(np.float32) - (np.float32(0.0) if integer else np.float32(37.0))
+    np.testing.assert_array_equal(_keys(ctx, vol, 3.0, integer), oracle.blockmatch(f, SIGMA, 3.0))
+
+
+def test_pipeline_with_forced_carry_equals_the_default(ctx, carry):
+    """Whole uint16 pipeline with the carry forced on a small volume: the result of the launch without it
+    (same tables; the stage kernels' global fp32 adds are not ordered, so near-ties may round apart)."""
+    from aind_exaspim_image_compression.bm4d import denoise_volume
+    vol = synth_volume((96, 48, 56), seed=33, as_u16=True)[0]
+    carry(0)
+    want = denoise_volume(vol, SIGMA, 37.0)
+    carry(2)
+    d = np.abs(denoise_volume(vol, SIGMA, 37.0).astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (int(d.max()), float(np.mean(d > 0)))
+
+
+def test_large_launch_takes_the_carry_by_default_and_agrees(ctx, carry):
+    """128 x 640 x 640: 23 x 23 tiles per slab, 4 slabs with the carry (31 reference layers) against 5
+    without; the automatic setting (1) must give the tables of the launch without it, from both kernels."""
+    rng = np.random.default_rng(12)
+    vol = np.clip(rng.normal(37.0, SIGMA, (128, 640, 640)), 0, 65535).round().astype(np.uint16)
+    vol[30:90, 100:300, 200:420] += 400
+    got = {}
+    for mode in (0, 1):
+        carry(mode)
+        got[mode] = (_keys(ctx, vol, 3.0, True), _keys(ctx, vol, 0.6, False))
+    np.testing.assert_array_equal(got[0][0], got[1][0])
+    np.testing.assert_array_equal(got[0][1], got[1][1])
