@@ -103,18 +103,31 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ vol_all, VolGeom g,
                                                       uint32_t keymax,
                                                       uint32_t* __restrict__ keys_all, int tiles_y,
-                                                      int tiles_x, int guarded, int xcd_q, Carry carry) {
+                                                      int tiles_x, int guarded, int xcd_q, int nbatch, Carry carry) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS,
                   PCOLS = TS::PCOLS, PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) float pbuf_all[TCZ][2][PBUF];
     __shared__ __align__(16) float lower0[2 * CARRY_ROUND + 64];   // wave 0's lower cell layer (from the carry), both rounds
 
-    const float* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
-    uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
-
-    const int tile = xcd_q ? xcd_slab_sync(blockIdx.x, tiles_y * tiles_x, xcd_q) : xcd_contiguous(blockIdx.x, gridDim.x);
-    if (tile < 0) return;                          // padding of the slab-synchronous order
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
+    // Tile order.  Slab order (xcd_q != 0): one slab = the tiles of ONE tz of all batch elements, all XCDs
+    // inside it (xcd_slab_sync); a column is (batch element, ty, tx).  Otherwise every XCD walks its own
+    // contiguous range of a batch element's tiles (blockIdx.y = batch element).
+    const int per = tiles_y * tiles_x, cols = per * nbatch;
+    int tz, col;
+    if (xcd_q) {
+        const int t = xcd_slab_sync(blockIdx.x, cols, xcd_q);
+        if (t < 0) return;                         // padding of the slab order
+        tz = t / cols;
+        col = t - tz * cols;
+    } else {
+        const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+        tz = t / per;
+        col = (int)blockIdx.y * per + (t - tz * per);
+    }
+    const int bi = col / per, pos = col - bi * per;
+    const int ty = pos / tiles_x, tx = pos - ty * tiles_x;
+    const float* __restrict__ vol = vol_all + (size_t)bi * (size_t)g.nvox;
+    uint32_t* __restrict__ keys = keys_all + (size_t)bi * (size_t)g.nref * MAXG;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int cx = lane % TCX, cy = lane / TCX, cz = __builtin_amdgcn_readfirstlane(tid >> 6);   // cz == wave index
@@ -125,9 +138,9 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // cell layers a tile advances by (CARRY above); this tile's column and its two carry slots
     const int Ls = (carry.on ? TCZ : TCZ - 1) * tz;
     constexpr int nb = 1;
-    const int pos = ty * tiles_x + tx, per = tiles_y * tiles_x;
-    const float* carry_rd = reinterpret_cast<const float*>(carry.buf) + ((size_t)((tz + 1) & 1) * per + pos) * CARRY_TILE;
-    float* carry_wr = reinterpret_cast<float*>(carry.buf) + ((size_t)(tz & 1) * per + pos) * CARRY_TILE;
+    const float* carry_rd = reinterpret_cast<const float*>(carry.buf) + ((size_t)((tz + 1) & 1) * cols + col) * CARRY_TILE;
+    float* carry_wr = reinterpret_cast<float*>(carry.buf) + ((size_t)(tz & 1) * cols + col) * CARRY_TILE;
+    int* done_col = carry.done + col;
 
     // Cell origin; cells beyond the volume are clamped inside it (their sums are never used).
     const int qy = min(STEP * iy, g.ny - STEP), qx = min(STEP * ix, g.nx - STEP);
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const bool lower_carried = carry.on && cz == 0 && tz > 0;          // the lower layer is the tile below's top layer
     const bool carries = carry.on && cz == TCZ - 1 && L + 1 <= g.az;   // ... and this wave's sums are the next tile's
     const bool ref_ok = ref_yx && active && (cz > 0 || lower_carried);
-    if ((lower_carried || carries) && tz > 0) carry_wait_for(carry.done + pos, tz, lane);
+    if ((lower_carried || carries) && tz > 0) carry_wait_for(done_col, tz, lane);
     const int rz = STEP * iz;
 
     uint32_t list[MAXG];
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
         // the tile is finished when wave 7's stores have been acknowledged and wave 0's last prefetch has landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(carry.done + pos, tz + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(done_col, tz + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -455,18 +468,29 @@ template <class TS>
 __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restrict__ vol_all, VolGeom g,
                                                         uint32_t keymax,
                                                         uint32_t* __restrict__ keys_all, int tiles_y,
-                                                        int tiles_x, int xcd_q, Carry carry) {
+                                                        int tiles_x, int xcd_q, int nbatch, Carry carry) {
     constexpr int TCX = TS::TCX, TRX = TS::TRX, TRY = TS::TRY, PROWS = TS::PROWS, PCOLS = TS::PCOLS,
                   PSTR = TS::PSTR, PCH = TS::PCH, NDMA = TS::NDMA, PBUF = TS::PBUF;
     __shared__ __align__(16) uint32_t pbuf_all[TCZ][2][PBUF];
     __shared__ __align__(16) uint32_t lower0[2 * CARRY_ROUND + 64];   // wave 0's lower cell layer (from the carry), both rounds
 
-    const uint16_t* __restrict__ vol = vol_all + (size_t)blockIdx.y * (size_t)g.nvox;
-    uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.y * (size_t)g.nref * MAXG;
-
-    const int tile = xcd_q ? xcd_slab_sync(blockIdx.x, tiles_y * tiles_x, xcd_q) : xcd_contiguous(blockIdx.x, gridDim.x);
-    if (tile < 0) return;                          // padding of the slab-synchronous order
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, tz = tile / (tiles_x * tiles_y);
+    // tile order: see bm_tile_kernel
+    const int per = tiles_y * tiles_x, cols = per * nbatch;
+    int tz, col;
+    if (xcd_q) {
+        const int t = xcd_slab_sync(blockIdx.x, cols, xcd_q);
+        if (t < 0) return;                         // padding of the slab order
+        tz = t / cols;
+        col = t - tz * cols;
+    } else {
+        const int t = xcd_contiguous(blockIdx.x, gridDim.x);
+        tz = t / per;
+        col = (int)blockIdx.y * per + (t - tz * per);
+    }
+    const int bi = col / per, pos = col - bi * per;
+    const int ty = pos / tiles_x, tx = pos - ty * tiles_x;
+    const uint16_t* __restrict__ vol = vol_all + (size_t)bi * (size_t)g.nvox;
+    uint32_t* __restrict__ keys = keys_all + (size_t)bi * (size_t)g.nref * MAXG;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int cx = lane % TCX, cy = lane / TCX, cz = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -476,9 +500,9 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     // cell layers a tile advances by (CARRY above); this tile's column and its two carry slots
     const int Ls = (carry.on ? TCZ : TCZ - 1) * tz;
     constexpr int nb = 1;
-    const int pos = ty * tiles_x + tx, per = tiles_y * tiles_x;
-    const uint32_t* carry_rd = carry.buf + ((size_t)((tz + 1) & 1) * per + pos) * CARRY_TILE;
-    uint32_t* carry_wr = carry.buf + ((size_t)(tz & 1) * per + pos) * CARRY_TILE;
+    const uint32_t* carry_rd = carry.buf + ((size_t)((tz + 1) & 1) * cols + col) * CARRY_TILE;
+    uint32_t* carry_wr = carry.buf + ((size_t)(tz & 1) * cols + col) * CARRY_TILE;
+    int* done_col = carry.done + col;
 
     const int qy = min(STEP * iy, g.ny - STEP), qx = min(STEP * ix, g.nx - STEP);
     // staged window: rows Y0 + dylo ..., columns X0 ... with X0 even (one column more to the left
@@ -504,7 +528,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     const bool lower_carried = carry.on && cz == 0 && tz > 0;          // the lower layer is the tile below's top layer
     const bool carries = carry.on && cz == TCZ - 1 && L + 1 <= g.az;   // ... and this wave's sums are the next tile's
     const bool ref_ok = ref_yx && active && (cz > 0 || lower_carried);
-    if ((lower_carried || carries) && tz > 0) carry_wait_for(carry.done + pos, tz, lane);
+    if ((lower_carried || carries) && tz > 0) carry_wait_for(done_col, tz, lane);
     const int rz = STEP * iz;
 
     uint32_t list[MAXG];
@@ -714,7 +738,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         // the tile is finished when wave 7's stores have been acknowledged and wave 0's last prefetch has landed
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(carry.done + pos, tz + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(done_col, tz + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -810,7 +834,7 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // has a few tiles per CU).
 int g_bm_xcd_mode = 1;
 // Carry between the tiles of a column (CARRY above): 0 = off (tiles advance by seven cell layers), 1 = on
-// where the launch runs in slab order, 2 = slab order and carry forced (tests: small volumes).
+// wherever it saves a tile per column, 2 = on whenever a column has two tiles (tests).
 int g_bm_carry = 1;
 
 struct TilePlan {
@@ -820,12 +844,16 @@ static TilePlan plan_tiles(const VolGeom& g, int batch, int try_, int trx, bool 
     TilePlan p;
     p.ty = (g.ay + try_ - 1) / try_;
     p.tx = (g.ax + trx - 1) / trx;
-    const long long per = (long long)p.ty * p.tx;
+    const long long cols = (long long)p.ty * p.tx * batch;          // columns of tiles: (batch element, ty, tx)
     const int tz7 = (g.az + TCZ - 2) / (TCZ - 1), tz8 = g.az / TCZ + 1;
-    const bool slab = g_bm_xcd_mode != 0 && per >= 512;
-    p.carry = (have_carry && batch == 1 && g_bm_carry != 0 && ((slab && tz8 >= 2) || g_bm_carry == 2)) ? 1 : 0;
+    const bool slab = g_bm_xcd_mode != 0 && cols >= 512;
+    // The carry pays where it saves a tile per column (a 64^3 patch: 15 reference layers = 3 tiles without,
+    // 2 with) AND a slab is a couple of rounds of the 256 CUs: a tile waits for the tile below it, and when
+    // both are resident together the upper one only spins on a CU (a single small volume gains nothing).
+    const bool worth = tz8 >= 2 && tz8 < tz7 && slab;
+    p.carry = (have_carry && g_bm_carry != 0 && (worth || (g_bm_carry == 2 && tz8 >= 2))) ? 1 : 0;
     p.tz = p.carry ? tz8 : tz7;
-    p.xq = (p.carry || (slab && p.tz >= 2)) ? (int)((per + 7) / 8) : 0;
+    p.xq = (p.carry || (slab && p.tz >= 2)) ? (int)((cols + 7) / 8) : 0;
     return p;
 }
 // Tile shape: fewer (y, x) tiles = fewer idle cell lanes (64^3 patches: 5 flat tiles against 9 cubes)
@@ -842,8 +870,8 @@ size_t bm_carry_bytes(const VolGeom& g, int batch) {
     const bool flat = flat_tiles<TileShape<8, 8>, TileShape<4, 16>>(g);
     const TilePlan p = plan_tiles(g, batch, flat ? 3 : 7, flat ? 15 : 7, true);
     if (!p.carry) return 0;
-    const size_t per = (size_t)p.ty * p.tx;
-    return 2 * per * CARRY_TILE * sizeof(uint32_t) + per * sizeof(int);
+    const size_t cols = (size_t)p.ty * p.tx * (size_t)batch;
+    return 2 * cols * CARRY_TILE * sizeof(uint32_t) + cols * sizeof(int);
 }
 
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
@@ -860,13 +888,13 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         Carry carry;
         carry.on = p.carry;
         carry.buf = static_cast<uint32_t*>(carry_mem);
-        const size_t per = (size_t)p.ty * p.tx;
-        carry.done = p.carry ? reinterpret_cast<int*>(carry.buf + 2 * per * CARRY_TILE) : nullptr;
+        const size_t cols = (size_t)p.ty * p.tx * (size_t)batch;
+        carry.done = p.carry ? reinterpret_cast<int*>(carry.buf + 2 * cols * CARRY_TILE) : nullptr;
         if (p.carry) {
-            hipError_t e = hipMemsetAsync(carry.done, 0, per * sizeof(int), stream);
+            hipError_t e = hipMemsetAsync(carry.done, 0, cols * sizeof(int), stream);
             if (e != hipSuccess) return e;
         }
-        dim3 grid((unsigned)(p.xq ? 8 * p.xq * p.tz : p.tz * p.ty * p.tx), (unsigned)batch);
+        dim3 grid((unsigned)(p.xq ? 8 * p.xq * p.tz : p.tz * p.ty * p.tx), (unsigned)(p.xq ? 1 : batch));
         using Cube16 = TileShape16<8, 8>;
         using Flat16 = TileShape16<4, 16>;
         using Cube = TileShape<8, 8>;
@@ -874,17 +902,17 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         if (vol16) {
             if (flat)
                 hipLaunchKernelGGL(bm_tile16_kernel<Flat16>, grid, dim3(512), 0, stream, vol16, g, keymax,
-                                   keys, p.ty, p.tx, p.xq, carry);
+                                   keys, p.ty, p.tx, p.xq, batch, carry);
             else
                 hipLaunchKernelGGL(bm_tile16_kernel<Cube16>, grid, dim3(512), 0, stream, vol16, g, keymax,
-                                   keys, p.ty, p.tx, p.xq, carry);
+                                   keys, p.ty, p.tx, p.xq, batch, carry);
         } else {
             if (flat)
                 hipLaunchKernelGGL(bm_tile_kernel<Flat>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                                   p.ty, p.tx, guarded, p.xq, carry);
+                                   p.ty, p.tx, guarded, p.xq, batch, carry);
             else
                 hipLaunchKernelGGL(bm_tile_kernel<Cube>, grid, dim3(512), 0, stream, vol, g, keymax, keys,
-                                   p.ty, p.tx, guarded, p.xq, carry);
+                                   p.ty, p.tx, guarded, p.xq, batch, carry);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

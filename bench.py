@@ -392,6 +392,7 @@ def run_slabs(args, rank, local_rank, world, dist):
     raw = torch.from_numpy(host.view(np.int16)).to(dev)
     den = SlabDenoiser(host.shape, SIGMA, dev)
     ctx = den.ctx
+    apply_env_options(ctx)
     own = (plan.z1 - plan.z0, n, n)
     encode, sz16 = torch_encode_legs(ctx, own, dev)
 
@@ -464,6 +465,7 @@ def run_chunks(args, rank, local_rank, world, dist):
     del host
     raw = torch.zeros((plan.p1 - plan.p0, py, px), dtype=torch.int16, device=dev)
     den = ChunkedSlabDenoiser(SIGMA, OFFSET, dev, chunk=chunk, halo=halo)
+    apply_env_options(den.ctx)
     own_shape = (plan.z1 - plan.z0, py, px)
     encode, sz16 = torch_encode_legs(den.ctx, own_shape, dev)
 
@@ -516,6 +518,21 @@ def run_chunks(args, rank, local_rank, world, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+ENV_OPTIONS = {                      # A/B switches of tools/dbg: environment variable -> exabm4d_set_option name
+    "EXABM4D_STAGE_CHUNKS": "stage_chunks",      # z chunks of the stage kernels
+    "EXABM4D_STAGE_PAIRVOL": "stage_pairvol",    # Wiener gathers from the interleaved (noisy, basic) volume
+    "EXABM4D_STAGE_QUADS": "stage_quads",        # Wiener stage on teams of 4 (1) or 2 (0) waves
+    "EXABM4D_BM_CARRY": "bm_carry",              # block matching: carry between the tiles of a column
+    "EXABM4D_BM_XCD_MODE": "bm_xcd_mode",        # block matching: workgroup order
+}
+
+
+def apply_env_options(ctx):
+    for var, name in ENV_OPTIONS.items():
+        if os.environ.get(var):
+            ctx.set_option(name, int(os.environ[var]))
 
 
 _RESULT_FD = None
@@ -716,12 +733,7 @@ def main():
         ctx.record(ev[3])
 
     ctx.set_option("profile", 1)
-    if os.environ.get("EXABM4D_STAGE_CHUNKS"):           # diagnostic sweep (tools/dbg)
-        ctx.set_option("stage_chunks", int(os.environ["EXABM4D_STAGE_CHUNKS"]))
-    if os.environ.get("EXABM4D_STAGE_PAIRVOL"):          # A/B: Wiener gathers from the interleaved volume (1) or not (0)
-        ctx.set_option("stage_pairvol", int(os.environ["EXABM4D_STAGE_PAIRVOL"]))
-    if os.environ.get("EXABM4D_STAGE_QUADS"):            # A/B: Wiener stage on teams of 4 (1) or 2 (0) waves
-        ctx.set_option("stage_quads", int(os.environ["EXABM4D_STAGE_QUADS"]))
+    apply_env_options(ctx)
     for _ in range(args.warmup):
         step()
     barrier()

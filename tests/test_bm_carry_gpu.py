@@ -2,7 +2,7 @@
 cell layers instead of seven and takes the lower cells of its first reference layer from the tile below,
 through global memory, in slab order behind a per-column counter.  The same sums enter the same adds:
 tables must be bit-identical to the launch without the carry and to the oracle -- ragged last tiles, idle
-waves, both tile shapes, the float and the integer kernel, batches (which keep the old tiling)."""
+waves, both tile shapes, the float and the integer kernel, batches."""
 import numpy as np
 import pytest
 
@@ -61,9 +61,9 @@ def test_carried_tables_equal_tiled_tables_and_the_oracle(ctx, oracle, carry, sh
 
 @pytest.mark.parametrize("integer", [False, True])
 def test_carry_with_patches_batches_and_unaligned_planes(ctx, oracle, carry, integer):
-    """A 64^3 patch takes the 4 x 16 tile shape (15 reference layers = two tiles with the carry); a batch
-    keeps the tiling without it, whatever the option says; a 102-plane volume has a clamped last grid
-    position (generic kernel) next to its carried layers."""
+    """A 64^3 patch takes the 4 x 16 tile shape (15 reference layers = two tiles with the carry); in a batch
+    the columns of all elements form one slab (3 x 5 columns here); a 102-plane volume has a clamped last
+    grid position (generic kernel) next to its carried layers."""
     vols = np.stack([synth_volume((64, 64, 64), seed=70 + i, as_u16=True)[0] for i in range(3)])
     carry(2)
     f0 = vols[0].astype(np.float32) - (np.float32(0.0) if integer else np.float32(37.0))
