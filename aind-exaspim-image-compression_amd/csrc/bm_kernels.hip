@@ -871,7 +871,8 @@ size_t bm_carry_bytes(const VolGeom& g, int batch) {
     const TilePlan p = plan_tiles(g, batch, flat ? 3 : 7, flat ? 15 : 7, true);
     if (!p.carry) return 0;
     const size_t cols = (size_t)p.ty * p.tx * (size_t)batch;
-    return 2 * cols * CARRY_TILE * sizeof(uint32_t) + cols * sizeof(int);
+    const size_t need = 2 * cols * CARRY_TILE * sizeof(uint32_t) + cols * sizeof(int);
+    return need <= ((size_t)16 << 30) ? need : 0;        // 744 KB per column: beyond 16 GB the launch goes without
 }
 
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
