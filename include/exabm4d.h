@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXABM4D_VERSION 301 /* 0.3.1: + exabm4d_denoise_chunked_u16_host; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
+#define EXABM4D_VERSION 301 /* 0.3.1: + exabm4d_denoise_chunked_u16_host, options "bm_carry" / "bm_xcd_mode"; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
 
 typedef enum exabm4d_status {
     EXABM4D_OK = 0,
@@ -124,8 +124,13 @@ int exabm4d_default_params(exabm4d_params* p);
  * Wiener stage on teams of four waves per group (default 0: measured slower);
  * "bm_int" = 0 keeps the uint16 pipelines' stage-1 matching on the float kernel; "stage_chunks",
  * "chunk_budget_mb", "profile": z chunks of the stage kernels (0 = automatic), scratch budget of the
- * chunk-local mode, per-phase HIP events for exabm4d_profile_read.  "stage_pairvol", "stage_quads" and
- * "stage_chunks" are process-wide. */
+ * chunk-local mode, per-phase HIP events for exabm4d_profile_read.  "bm_carry" = 0 | 1 | 2 (default 1):
+ * block matching's tiles hand their top cell layer to the tile above through device memory, eight
+ * reference layers per tile instead of seven (1: where it saves a tile per column and the launch is large
+ * enough, 2: wherever a column has two tiles; needs 744 KB of device memory per tile column, allocated on
+ * first use; tables are identical); "bm_xcd_mode" = 0 | 1 (default 1): workgroup order of
+ * block matching.  "stage_pairvol", "stage_quads", "stage_chunks", "bm_carry" and
+ * "bm_xcd_mode" are process-wide. */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
 /* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
  * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and
