@@ -101,3 +101,28 @@ def test_large_launch_takes_the_carry_by_default_and_agrees(ctx, carry):
         got[mode] = (_keys(ctx, vol, 3.0, True), _keys(ctx, vol, 0.6, False))
     np.testing.assert_array_equal(got[0][0], got[1][0])
     np.testing.assert_array_equal(got[0][1], got[1][1])
+
+
+@pytest.mark.parametrize("integer", [False, True])
+def test_large_batch_of_patches_takes_the_carry_by_default(ctx, carry, integer):
+    """120 patches of 64^3 (the shape of scripts/precompute.py's work): 600 columns in one slab, two tiles per
+    column with the carry instead of three -- the automatic setting against the launch without it, every
+    element; and the chunk-local mode's batches of padded chunks through the whole pipeline."""
+    rng = np.random.default_rng(5)
+    base = np.stack([synth_volume((64, 64, 64), seed=200 + i, as_u16=True)[0] for i in range(6)])
+    vols = np.ascontiguousarray(base[rng.integers(0, 6, 120)])
+    vols += rng.integers(0, 3, vols.shape, dtype=np.uint16)            # 120 different patches
+    carry(0)
+    want = _keys(ctx, vols, 3.0, integer, batch=120)
+    carry(1)
+    np.testing.assert_array_equal(_keys(ctx, vols, 3.0, integer, batch=120), want)
+
+
+def test_chunk_local_mode_with_and_without_the_carry(ctx, carry):
+    from aind_exaspim_image_compression.bm4d import denoise_chunked
+    vol = synth_volume((72, 200, 200), seed=41, as_u16=True)[0]        # 2 x 5 x 5 cores of 40 + 8: 14 reference layers
+    carry(0)
+    want = denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8)
+    carry(2)
+    d = np.abs(denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8).astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (int(d.max()), float(np.mean(d > 0)))
