@@ -110,3 +110,57 @@ def test_differences_come_from_stage2_tables_not_from_rounding_of_half_offsets(c
           f"{np.mean(foot[diff]):.1%} inside the footprint of a changed table; unexplained {int(unexplained.sum())}")
     assert not unexplained.any()
     assert np.mean(foot[diff]) > 0.5 and foot.mean() < 0.9            # the footprint is not "everywhere"
+
+
+def test_one_changed_group_next_to_a_bright_box_moves_voxels_by_several_counts(ctx, oracle):
+    """The volume that tripped tools/fuzz_parity.py (seed 11, iteration 220) in round 3: N(40, 24) noise with
+    one 9 x 11 x 7 box of 9059 counts, sigma 16, offset 0.  ONE stage-2 group of ~1000 differs between GPU and
+    oracle (the last bits of the basic estimate moved a candidate across the admission bound); its blocks
+    straddle the box's edge, so 0.09 % of the voxels move by 2 .. 4 counts.  The account of the test above
+    holds: same basic estimate -> identical tables; every differing voxel lies in the footprint of the changed
+    group or on a rounding near-tie.  (tools/fuzz_parity.py applies this account whenever its plain bound fails.)"""
+    vol = np.load(os.path.join(HERE, "golden", "fuzz_sparse_volume.npz"))["vol"]
+    sigma, shape, n = 16.0, vol.shape, vol.size
+    f = vol.astype(np.float32)
+    basic_o = oracle.bm4d(f, sigma, stages=1).astype(np.float32)
+    pre_o = oracle.bm4d(f, sigma, stages=2).astype(np.float32)
+    want = _to_u16(pre_o)
+    g = _grid(shape)
+
+    def keys_of(basic):
+        d_vol, d_keys = ctx.to_device(basic), ctx.alloc(g[0] * g[1] * g[2] * 64)
+        try:
+            ctx.blockmatch(d_vol, shape, sigma, 0.6, d_keys)
+            ctx.sync()
+            return d_keys.download((g[0], g[1], g[2], 16), np.uint32)
+        finally:
+            d_vol.free()
+            d_keys.free()
+
+    keys_o = oracle.blockmatch(basic_o, sigma, 0.6)
+    np.testing.assert_array_equal(keys_of(basic_o), keys_o)
+    d_in, d_out = ctx.to_device(f), ctx.alloc(4 * n)
+    ctx.denoise_f32(d_in, d_out, shape, sigma, stages=1)
+    ctx.sync()
+    basic_g = d_out.download(shape, np.float32)
+    d_in.free()
+    d_out.free()
+    changed = np.any((keys_of(basic_g) & 0x7FF) != (keys_o & 0x7FF), axis=-1)
+    d_u, d_o = ctx.to_device(vol), ctx.alloc(vol.nbytes)
+    ctx.denoise_u16(d_u, d_o, shape, sigma, 0.0)
+    ctx.sync()
+    got = d_o.download(shape, np.uint16).astype(np.int64)
+    d_u.free()
+    d_o.free()
+    diff = got != want
+    foot = np.zeros(shape, bool)
+    pz, py, px = (_native.grid_positions(m) for m in shape)
+    for iz, iy, ix in zip(*np.nonzero(changed)):
+        z, y, x = int(pz[iz]), int(py[iy]), int(px[ix])
+        foot[max(0, z - 5):z + 13, max(0, y - 5):y + 13, max(0, x - 5):x + 13] = True
+    unexplained = diff & ~foot & (_tie_distance(pre_o) > 2e-5 * 65535.0)
+    print(f"groups changed {int(changed.sum())} of {changed.size}; max|d| {int(np.abs(got - want).max())}; "
+          f"differing {diff.mean():.2e}; unexplained {int(unexplained.sum())}")
+    assert not unexplained.any()
+    assert changed.sum() <= 0.01 * changed.size and diff.mean() < 2e-2
+    assert np.abs(got - want).max() <= 8          # bounded by the contrast the changed group's blocks straddle
