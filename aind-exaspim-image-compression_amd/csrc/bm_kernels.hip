@@ -15,8 +15,8 @@
 namespace exabm4d {
 
 // ------------------------------------------------------------------------------------------------
-// Tile kernel: 512 lanes = 8x8x8 cells; tiles overlap by one cell so a tile yields 7x7x7
-// grid-aligned reference blocks.
+// Tile kernel: 512 lanes = 8x8x8 cells; tiles overlap by one cell in y and x so a tile yields 7x7
+// grid-aligned reference blocks per layer, and 7 layers -- or 8 with the carry between tiles (CARRY below).
 // ------------------------------------------------------------------------------------------------
 // 16-byte load from a 4-byte aligned address (gfx950 global loads need only dword alignment;
 // hipcc emits global_load_dwordx4 for this type).
@@ -25,7 +25,6 @@ struct __attribute__((packed, aligned(4))) float4u {
 };
 
 constexpr int TCZ = 8;       // cell layers per tile = waves per workgroup
-// (TCZ cell layers give TCZ - 1 reference layers -- or TCZ with the carry below)
 constexpr int NE = 6;        // dy values per pass (two passes: dy = -5..0 and 1..6, 6 is masked)
 constexpr int NSTEP = SWIN * 2 * 4;             // (dz, pass, z) steps
 // A wave is one z-layer of TCY x TCX cells (64 lanes).  8 x 8 is the shape for volumes; 4 x 16
@@ -137,7 +136,6 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 
     // cell layers a tile advances by (CARRY above); this tile's column and its two carry slots
     const int Ls = (carry.on ? TCZ : TCZ - 1) * tz;
-    constexpr int nb = 1;
     const float* carry_rd = reinterpret_cast<const float*>(carry.buf) + ((size_t)((tz + 1) & 1) * cols + col) * CARRY_TILE;
     float* carry_wr = reinterpret_cast<float*>(carry.buf) + ((size_t)(tz & 1) * cols + col) * CARRY_TILE;
     int* done_col = carry.done + col;
@@ -164,8 +162,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
         xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
 
     const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
-#pragma unroll 1
-    for (int blk = 0; blk < nb; blk++) {
+    do {   // once; `break` = an idle wave skips the tile's work, not the barriers and the tail below
     const int L = Ls + cz;                             // this wave's cell layer
     const bool active = L <= g.az;
     const int iz = L - 1;                              // the reference layer it owns (lower cells: wave cz - 1)
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     // only keeps the workgroup's barrier count: four per (dz, pass).
     if (!active) {
         for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
-        continue;
+        break;
     }
 
     if (xin)
@@ -416,7 +413,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
             *reinterpret_cast<uint4*>(out + k) = v;
         }
     }
-    }   // blocks of the segment
+    } while (false);
 
     if (carry.on) {
         // the tile is finished when wave 7's stores have been acknowledged and wave 0's last prefetch has landed
@@ -499,7 +496,6 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 
     // cell layers a tile advances by (CARRY above); this tile's column and its two carry slots
     const int Ls = (carry.on ? TCZ : TCZ - 1) * tz;
-    constexpr int nb = 1;
     const uint32_t* carry_rd = carry.buf + ((size_t)((tz + 1) & 1) * cols + col) * CARRY_TILE;
     uint32_t* carry_wr = carry.buf + ((size_t)(tz & 1) * cols + col) * CARRY_TILE;
     int* done_col = carry.done + col;
@@ -518,8 +514,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         xmask |= ((rx + d - RAD >= 0) && (rx + d - RAD <= g.nx - BLK)) ? (1u << d) : 0u;
     const bool yin = (Y0 - RAD >= 0) && (Y0 + 1 + PROWS - 1 <= g.ny - 1);
 
-#pragma unroll 1
-    for (int blk = 0; blk < nb; blk++) {
+    do {   // once; `break` = an idle wave skips the tile's work, not the barriers and the tail below
     const int L = Ls + cz;                             // this wave's cell layer
     const bool active = L <= g.az;                     // cell layers 0 .. az exist
     const int iz = L - 1;                              // ... and the reference layer it owns
@@ -561,7 +556,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
         // a wave whose cell layer lies beyond the last one any reference block uses only keeps the
         // workgroup's barrier count: four per (dz, pass)
         for (int i = 0; i < (NSTEP / 4) * 4; i++) __syncthreads();
-        continue;
+        break;
     }
     issue_dma(0, pbuf_all[cz][0]);
 
@@ -732,7 +727,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
             *reinterpret_cast<uint4*>(out + k) = v;
         }
     }
-    }   // blocks of the segment
+    } while (false);
 
     if (carry.on) {
         // the tile is finished when wave 7's stores have been acknowledged and wave 0's last prefetch has landed
