@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -935,7 +936,7 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
         w0 = std::max(0, c0 - halo);
         w1 = std::min(nz, c1 + halo);
     };
-    std::thread uploader([&]() {
+    auto upload_layers = [&]() {
         if (hipSetDevice(device) != hipSuccess) return st.fail_with("uploader: hipSetDevice");
         for (int k = 0; k < layers; k++) {
             if (k >= 2) {       // window k & 1 was read by layer k - 2
@@ -950,8 +951,8 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
             if (r != hipSuccess) return st.fail_with(std::string("upload of a chunk layer: ") + hipGetErrorString(r));
             st.advance(&StreamedLayers::uploaded);
         }
-    });
-    std::thread downloader([&]() {
+    };
+    auto download_layers = [&]() {
         if (hipSetDevice(device) != hipSuccess) return st.fail_with("downloader: hipSetDevice");
         for (int k = 0; k < layers; k++) {
             if (!st.wait_for(&StreamedLayers::enqueued, k + 1)) return;
@@ -965,7 +966,18 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
             if (r != hipSuccess) return st.fail_with(std::string("download of a chunk layer: ") + hipGetErrorString(r));
             st.advance(&StreamedLayers::downloaded);
         }
-    });
+    };
+    // no C++ exception may cross the C boundary: a thread that cannot be started is an error code
+    std::thread uploader, downloader;
+    try {
+        uploader = std::thread(upload_layers);
+        downloader = std::thread(download_layers);
+    } catch (const std::exception& ex) {
+        st.fail_with(std::string("cannot start a copy thread: ") + ex.what());
+        if (uploader.joinable()) uploader.join();
+        release();
+        return fail(ctx, EXABM4D_ERR_NOMEM, "streamed chunk mode: " + st.err);
+    }
 
     std::string compute_err;
     for (int k = 0; k < layers; k++) {
