@@ -862,8 +862,10 @@ static bool flat_tiles(const VolGeom& g) {
 size_t bm_carry_bytes(const VolGeom& g, int batch) {
     if (g.az <= 0 || g.ay <= 0 || g.ax <= 0) return 0;
     // the same decision the launcher takes (the float and the integer kernel share tile shapes)
-    const bool flat = flat_tiles<TileShape<8, 8>, TileShape<4, 16>>(g);
-    const TilePlan p = plan_tiles(g, batch, flat ? 3 : 7, flat ? 15 : 7, true);
+    using Cube = TileShape<8, 8>;
+    using Flat = TileShape<4, 16>;
+    const bool flat = flat_tiles<Cube, Flat>(g);
+    const TilePlan p = plan_tiles(g, batch, flat ? Flat::TRY : Cube::TRY, flat ? Flat::TRX : Cube::TRX, true);
     if (!p.carry) return 0;
     const size_t cols = (size_t)p.ty * p.tx * (size_t)batch;
     const size_t need = 2 * cols * CARRY_TILE * sizeof(uint32_t) + cols * sizeof(int);
@@ -877,10 +879,15 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
     // checked that the integer kernel gives the float kernel's tables (keymax <= 2^24, nx even)
     // carry_mem: bm_carry_bytes(g, batch) of device memory, or nullptr (tiles advance by seven layers)
     if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
-        const bool flat = flat_tiles<TileShape<8, 8>, TileShape<4, 16>>(g);
-        static_assert(TileShape<8, 8>::TRY == TileShape16<8, 8>::TRY && TileShape<4, 16>::TRX == TileShape16<4, 16>::TRX,
-                      "one tile plan for both kernels");
-        const TilePlan p = plan_tiles(g, batch, flat ? 3 : 7, flat ? 15 : 7, carry_mem != nullptr);
+        using Cube16 = TileShape16<8, 8>;
+        using Flat16 = TileShape16<4, 16>;
+        using Cube = TileShape<8, 8>;
+        using Flat = TileShape<4, 16>;
+        static_assert(Cube::TRY == Cube16::TRY && Cube::TRX == Cube16::TRX && Flat::TRY == Flat16::TRY &&
+                      Flat::TRX == Flat16::TRX, "one tile plan for both kernels");
+        const bool flat = flat_tiles<Cube, Flat>(g);
+        const TilePlan p = plan_tiles(g, batch, flat ? Flat::TRY : Cube::TRY, flat ? Flat::TRX : Cube::TRX,
+                                      carry_mem != nullptr);
         Carry carry;
         carry.on = p.carry;
         carry.buf = static_cast<uint32_t*>(carry_mem);
@@ -891,10 +898,6 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
             if (e != hipSuccess) return e;
         }
         dim3 grid((unsigned)(p.xq ? 8 * p.xq * p.tz : p.tz * p.ty * p.tx), (unsigned)(p.xq ? 1 : batch));
-        using Cube16 = TileShape16<8, 8>;
-        using Flat16 = TileShape16<4, 16>;
-        using Cube = TileShape<8, 8>;
-        using Flat = TileShape<4, 16>;
         if (vol16) {
             if (flat)
                 hipLaunchKernelGGL(bm_tile16_kernel<Flat16>, grid, dim3(512), 0, stream, vol16, g, keymax,

@@ -896,6 +896,12 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
     if (stages != 1 && stages != 2) return fail(ctx, EXABM4D_ERR_INVALID, "stages must be 1 or 2");
     if (nz < 1 || ny < 1 || nx < 1 || chunk < 1 || halo < 0 || halo > 64)
         return fail(ctx, EXABM4D_ERR_INVALID, "chunked: sizes >= 1, chunk >= 1, 0 <= halo <= 64");
+    {   // the downloads of early layers would overwrite planes that later layers still have to upload
+        const size_t bytes = (size_t)nz * (size_t)ny * (size_t)nx * sizeof(uint16_t);
+        const char *a = reinterpret_cast<const char*>(in), *b = reinterpret_cast<const char*>(out);
+        if (a < b + bytes && b < a + bytes)
+            return fail(ctx, EXABM4D_ERR_INVALID, "streamed chunk mode: input and output arrays overlap");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int layers = (nz + chunk - 1) / chunk;
     const size_t plane = (size_t)ny * (size_t)nx;

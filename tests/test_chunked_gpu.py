@@ -158,6 +158,13 @@ def test_streamed_host_volume_errors(ctx):
         denoise_chunked_streamed(vol, SIGMA, OFFSET, out=np.empty((24, 24, 25), np.uint16))
     with pytest.raises((ValueError, RuntimeError)):
         denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=4, halo=1)               # padded chunk thinner than a block
+    # the C entry point checks the overlap itself (a caller that is not the Python wrapper)
+    import ctypes
+    from aind_exaspim_image_compression import _native as nat
+    p = nat.default_params()
+    rc = nat.lib().exabm4d_denoise_chunked_u16_host(ctx.handle, vol.ctypes.data, vol.ctypes.data + 2 * 24 * 24, 20, 24, 24,
+                                                     16, 8, SIGMA, OFFSET, ctypes.byref(p), 2)
+    assert rc != 0 and b"overlap" in nat.lib().exabm4d_last_error(ctx.handle)
     # the context is usable afterwards
     close_u16(denoise_chunked_streamed(vol, SIGMA, OFFSET, chunk=16, halo=8),
               denoise_chunked(vol, SIGMA, OFFSET, chunk=16, halo=8))
