@@ -369,7 +369,7 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "bm_xcd_mode") == 0) {        // block matching's workgroup order (bm_kernels.hip)
-        g_bm_xcd_mode = value ? 1 : 0;
+        g_bm_xcd_mode = value < 0 ? 0 : (value > 16 ? 16 : value);   // >= 2: strips of that many tile rows
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "stage_quads") == 0) {        // Wiener stage: four (1) or two (0) waves per group

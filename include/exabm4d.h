@@ -128,7 +128,7 @@ int exabm4d_default_params(exabm4d_params* p);
  * block matching's tiles hand their top cell layer to the tile above through device memory, eight
  * reference layers per tile instead of seven (1: where it saves a tile per column and the launch is large
  * enough, 2: wherever a column has two tiles; needs 744 KB of device memory per tile column, allocated on
- * first use; tables are identical); "bm_xcd_mode" = 0 | 1 (default 1): workgroup order of
+ * first use; tables are identical); "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
  * block matching.  "stage_pairvol", "stage_quads", "stage_chunks", "bm_carry" and
  * "bm_xcd_mode" are process-wide. */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);

@@ -521,9 +521,10 @@ def test_wiener_gathers_from_the_interleaved_volume(ctx, oracle):
 
 
 def test_block_matching_workgroup_orders_give_identical_tables(ctx):
-    """bm_xcd_mode: 0 = every XCD walks its own contiguous range of tiles, 1 (default for large launches) =
-    all XCDs inside one z slab of tiles at a time, with padding workgroups that exit at once.  64 x 640 x 640:
-    3 slabs of 23 x 23 tiles, 5 padding positions per slab.  Same tables from both kernels."""
+    """bm_xcd_mode: 0 = every XCD walks its own contiguous range of tiles, 1 = all XCDs inside one z slab of
+    tiles at a time (raster order, padding workgroups that exit at once), 2 (default for large launches) / 3 /
+    5 = the slab in strips of that many tile rows (23 rows: ragged last strips).  64 x 640 x 640: 3 slabs of
+    23 x 23 tiles, 7 padding positions per slab.  Same tables from both kernels."""
     rng = np.random.default_rng(11)
     vol = np.clip(rng.normal(37.0, SIGMA, (64, 640, 640)), 0, 65535).round().astype(np.uint16)
     vol[20:40, 100:300, 200:420] += 500
@@ -533,7 +534,7 @@ def test_block_matching_workgroup_orders_give_identical_tables(ctx):
     d_keys = ctx.alloc(g[0] * g[1] * g[2] * 16 * 4)
     got = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2, 3, 5):
             ctx.set_option("bm_xcd_mode", mode)
             ctx.blockmatch_u16(d_u16, vol.shape, SIGMA, 3.0, d_keys)
             ctx.sync()
@@ -542,9 +543,10 @@ def test_block_matching_workgroup_orders_give_identical_tables(ctx):
             ctx.sync()
             got[mode] = (a, d_keys.download((*g, 16), np.uint32))
     finally:
-        ctx.set_option("bm_xcd_mode", 1)
+        ctx.set_option("bm_xcd_mode", 2)
         for b in (d_u16, d_f32, d_keys):
             b.free()
-    np.testing.assert_array_equal(got[0][0], got[1][0])
-    np.testing.assert_array_equal(got[0][1], got[1][1])
+    for mode in (1, 2, 3, 5):
+        np.testing.assert_array_equal(got[0][0], got[mode][0], err_msg=f"integer kernel, mode {mode}")
+        np.testing.assert_array_equal(got[0][1], got[mode][1], err_msg=f"fp32 kernel, mode {mode}")
     assert (got[1][0][..., 0] & 0x7FF).max() == 0 and (got[1][0][..., 1] != 0xFFFFFFFF).mean() > 0.5   # self first, groups found

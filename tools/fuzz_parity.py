@@ -110,7 +110,7 @@ def main():
         f = vol.astype(np.float32) - np.float32(offset)
         # block matching's launch variants: carry between tiles forced / off, workgroup order (tables must not care)
         ctx.set_option("bm_carry", int(rng.choice([0, 2, 2])))
-        ctx.set_option("bm_xcd_mode", int(rng.integers(0, 2)))
+        ctx.set_option("bm_xcd_mode", int(rng.integers(0, 4)))
 
         # stage-1 tables (uint16 entry point: integer kernel where it applies)
         g = [len(_native.grid_positions(n)) for n in shape]
