@@ -847,8 +847,9 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // slabs of a large volume); 1 = all XCDs inside one slab of ty x tx tiles at a time (worth it once a slab
 // has a few tiles per CU), raster order inside the slab; n >= 2 = the same, the slab walked in strips of n
 // tile rows, column-major inside a strip: the 32 tiles an XCD works on together then form a 2-D patch
-// instead of one long row of tiles, a smaller set of cache lines (measured at 1024^3: fp32 kernel 109.4 ->
-// 107.5 ms with strips of 2, 108.7 with 3, 110.0 with 4; the integer kernel is indifferent).
+// instead of one long row of tiles, a smaller set of cache lines (measured at 1024^3 on a noisy volume: fp32
+// kernel 109.4 -> 107.5 ms with strips of 2, 108.7 with 3, 110.0 with 4; the integer kernel and the fp32 kernel
+// on the pipeline's smooth basic estimate are indifferent -- DESIGN.md 5.1d).
 int g_bm_xcd_mode = 2;
 // Carry between the tiles of a column (CARRY above): 0 = off (tiles advance by seven cell layers), 1 = on
 // wherever it saves a tile per column, 2 = on whenever a column has two tiles (tests).
