@@ -376,6 +376,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         g_stage_quads = value ? 1 : 0;
         return EXABM4D_OK;
     }
+    if (std::strcmp(name, "stage_strip") == 0) {        // tile-column order of the two-waves-per-group stage kernels (0 = raster, n = strips of n tile rows)
+        g_stage_strip = value > 0 ? value : 0;
+        return EXABM4D_OK;
+    }
     if (std::strcmp(name, "stage_chunks") == 0) {       // diagnostic: z chunks of the stage kernels
         g_stage_chunks = value > 0 ? value : 0;
         return EXABM4D_OK;

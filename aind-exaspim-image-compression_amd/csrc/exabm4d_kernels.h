@@ -63,6 +63,7 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
                              const uint16_t* vol16 = nullptr, void* carry_mem = nullptr);
 extern int g_stage_quads;    // Wiener stage: 1 = four waves per group (stage_quad_kernel), 0 = two (stage_half_kernel<true>)
+extern int g_stage_strip;    // stage kernels: tile columns walked in strips of n tile rows (0 = raster)
 extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chunk count (0 = automatic)
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,

@@ -522,6 +522,7 @@ def run_chunks(args, rank, local_rank, world, dist):
 
 ENV_OPTIONS = {                      # A/B switches of tools/dbg: environment variable -> exabm4d_set_option name
     "EXABM4D_STAGE_CHUNKS": "stage_chunks",      # z chunks of the stage kernels
+    "EXABM4D_STAGE_STRIP": "stage_strip",        # stage kernels: tile columns in strips of n tile rows
     "EXABM4D_STAGE_PAIRVOL": "stage_pairvol",    # Wiener gathers from the interleaved (noisy, basic) volume
     "EXABM4D_STAGE_QUADS": "stage_quads",        # Wiener stage on teams of 4 (1) or 2 (0) waves
     "EXABM4D_BM_CARRY": "bm_carry",              # block matching: carry between the tiles of a column

@@ -129,8 +129,10 @@ int exabm4d_default_params(exabm4d_params* p);
  * reference layers per tile instead of seven (1: where it saves a tile per column and the launch is large
  * enough, 2: wherever a column has two tiles; needs 744 KB of device memory per tile column, allocated on
  * first use; tables are identical); "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
- * block matching.  "stage_pairvol", "stage_quads", "stage_chunks", "bm_carry" and
- * "bm_xcd_mode" are process-wide. */
+ * block matching; "stage_strip" = 0 | n (default 3): tile-column order of the stage
+ * kernels (0 = raster, n = strips of n tile rows; same results up to the order of the global fp32 adds).
+ * "stage_pairvol", "stage_quads", "stage_chunks", "stage_strip", "bm_carry" and "bm_xcd_mode" are
+ * process-wide. */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
 /* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
  * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and
