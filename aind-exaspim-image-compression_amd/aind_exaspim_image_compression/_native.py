@@ -109,6 +109,7 @@ SIGNATURES = {
     "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_chunked_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, _F, _F, _PP,
                                              _I]),
+    "exabm4d_blockmatch_plan": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]),
     "exabm4d_denoise_chunked_u16_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
@@ -618,6 +619,20 @@ def check_host_volume_pair(src, dst):
         raise ValueError("the destination is read-only")
     if np.shares_memory(src, dst):
         raise ValueError("source and destination may not overlap")
+
+
+def blockmatch_plan(shape, batch=1):
+    """The launch block matching chooses for this geometry (host logic of libexabm4d.so, no GPU needed):
+    dict with the tile grid, the slab-order parameter, whether tiles carry their top cell layer upwards
+     and the device memory that takes."""
+    out = (ctypes.c_int32 * 6)()
+    nbytes = ctypes.c_uint64()
+    rc = lib().exabm4d_blockmatch_plan(int(shape[0]), int(shape[1]), int(shape[2]), int(batch), out,
+                                       ctypes.byref(nbytes))
+    if rc != 0:
+        raise ValueError("blockmatch_plan: %s" % lib().exabm4d_last_error(None).decode())
+    return {"tiles_z": out[0], "tiles_y": out[1], "tiles_x": out[2], "slab_order_q": out[3], "carry": bool(out[4]),
+            "flat_tiles": bool(out[5]), "carry_bytes": int(nbytes.value)}
 
 
 def device_count():

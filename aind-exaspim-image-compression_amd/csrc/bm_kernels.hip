@@ -895,6 +895,17 @@ size_t bm_carry_bytes(const VolGeom& g, int batch) {
     return need <= ((size_t)16 << 30) ? need : 0;        // 744 KB per column: beyond 16 GB the launch goes without
 }
 
+// The launch block matching would choose for this geometry: {tile slabs, tile rows, tile columns, slab-order
+// parameter (0 = contiguous per XCD), carry on, flat tile shape} -- host logic only, for the CPU tests.
+void bm_plan(const VolGeom& g, int batch, int out[6]) {
+    using Cube = TileShape<8, 8>;
+    using Flat = TileShape<4, 16>;
+    const bool flat = flat_tiles<Cube, Flat>(g);
+    const TilePlan p = plan_tiles(g, batch, flat ? Flat::TRY : Cube::TRY, flat ? Flat::TRX : Cube::TRX,
+                                  bm_carry_bytes(g, batch) != 0);
+    out[0] = p.tz; out[1] = p.ty; out[2] = p.tx; out[3] = p.xq; out[4] = p.carry; out[5] = flat ? 1 : 0;
+}
+
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
                              const uint16_t* vol16, void* carry_mem) {

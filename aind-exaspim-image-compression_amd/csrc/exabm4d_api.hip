@@ -471,6 +471,18 @@ int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512) {
     make_tables((double)p->kaiser_beta, dct64, win512);
     return EXABM4D_OK;
 }
+int exabm4d_blockmatch_plan(int nz, int ny, int nx, int batch, int32_t plan[6], uint64_t* carry_bytes) {
+    if (!plan || !carry_bytes) return EXABM4D_ERR_INVALID;
+    VolGeom g;
+    const int rc = make_geom(nullptr, nz, ny, nx, batch, g);
+    if (rc) return rc;
+    int out[6];
+    bm_plan(g, batch, out);
+    for (int i = 0; i < 6; i++) plan[i] = out[i];
+    *carry_bytes = (uint64_t)bm_carry_bytes(g, batch);
+    return EXABM4D_OK;
+}
+
 size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages) {
     if (nz < 8 || ny < 8 || nx < 8 || batch < 1) return 0;
     const size_t n = (size_t)nz * ny * nx * (size_t)batch;

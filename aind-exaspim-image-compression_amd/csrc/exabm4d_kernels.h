@@ -58,6 +58,7 @@ hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny
                          double C1, double C2, double* partials, double* out1, hipStream_t s);
 extern int g_bm_xcd_mode;    // block matching's workgroup order: 0 = contiguous per XCD, 1 = all XCDs in one z slab of tiles (raster), n >= 2 = in strips of n tile rows
 extern int g_bm_carry;       // block matching: tiles of a column hand their top cell layer upwards (0 off, 1 automatic, 2 forced)
+void bm_plan(const VolGeom& g, int batch, int out[6]);   // {tz, ty, tx, slab-order q, carry, flat}: the launch plan (host logic)
 size_t bm_carry_bytes(const VolGeom& g, int batch);   // device memory launch_blockmatch needs for that (0: launch without)
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXABM4D_VERSION 301 /* 0.3.1: + exabm4d_denoise_chunked_u16_host, options "bm_carry" / "bm_xcd_mode"; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
+#define EXABM4D_VERSION 302 /* 0.3.2: + exabm4d_blockmatch_plan, option "stage_strip"; 0.3.1: + exabm4d_denoise_chunked_u16_host, options "bm_carry" / "bm_xcd_mode"; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
 
 typedef enum exabm4d_status {
     EXABM4D_OK = 0,
@@ -174,6 +174,12 @@ int exabm4d_grid_positions(int n, int32_t* pos);
 int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512);
 /* Bytes of device scratch a denoise call of this shape needs (match table + num/den + basic). */
 size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages);
+
+/* The launch block matching chooses for a geometry (host logic only, no device call): plan = {tile slabs in z,
+ * tile rows, tile columns, slab-order parameter (0: every XCD walks its own contiguous range), carry between
+ * tiles on, flat 4 x 16 tile shape}; carry_bytes = device memory the context allocates for
+ * the carry (0 without).  Follows the process-wide options "bm_carry" / "bm_xcd_mode". */
+int exabm4d_blockmatch_plan(int nz, int ny, int nx, int batch, int32_t plan[6], uint64_t* carry_bytes);
 
 /* ---- BM4D staged entry points (parity hooks; a-B1 .. a-B6 of SURVEY.md section 8) ---------- */
 /* Block matching.  keys: [batch][nref][16] uint32, nref = gz*gy*gx in (z,y,x) raster of the
