@@ -58,7 +58,7 @@ struct TileShape {
 // slab tz - 1 is dispatched before any of slab tz), so the producer of a tile's carry started a whole
 // slab earlier; `done[column]` (tiles finished) makes that a guarantee instead of a likelihood: waves 0
 // and 7 wait for done >= tz before they read / overwrite a slot, and a workgroup never waits for a
-// later one, so the wait cannot deadlock.  All carry traffic is system-scope (stores written through,
+// later one, so the wait cannot deadlock (per XCD too: a slab position belongs to the same XCD in every slab).  All carry traffic is system-scope (stores written through,
 // loads and the LDS-DMA prefetch with sc0 sc1): no assumption about which XCD's L2 a tile runs on.  Wave 0
 // fetches a (dz, pass)'s two rounds by LDS-DMA one plane ahead of their use: no registers, no wait in
 // front of the exchange barriers.  The same sums enter the same adds: tables are unchanged.
