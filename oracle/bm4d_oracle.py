@@ -49,10 +49,23 @@ def lib():
         L.orc_group_transform.argtypes = [f32p, c_int, c_int]
         L.cpu_group_transform.argtypes = [f32p, c_int, c_int]
         L.cpu_group_transform.restype = None
-        L.orc_stage.argtypes = [f32p, f32p, u32p, c_int, c_int, c_int, c_f, c_f, c_d, f32p, f32p]
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        L.orc_stage.argtypes = [f32p, f32p, u32p, c_int, c_int, c_int, c_f, c_f, c_d, c_int, f32p, f32p]
+        L.orc_stage_q.argtypes = [f32p, f32p, u32p, c_int, c_int, c_int, c_f, c_f, c_d, c_int, i64p, i64p]
+        L.orc_stage_q.restype = None
+        L.orc_data_exp.argtypes = [f32p, c_sz]
+        L.orc_data_exp.restype = c_int
+        L.orc_rcp_nr.argtypes = [c_f]
+        L.orc_rcp_nr.restype = c_f
+        L.orc_den_from_corners.argtypes = [i64p, c_int, c_int, c_int, c_d, f32p]
+        L.orc_den_from_corners.restype = None
+        L.orc_num_to_float.argtypes = [i64p, c_sz, c_int, f32p]
+        L.orc_num_to_float.restype = None
         L.orc_normalize.argtypes = [f32p, f32p, f32p, c_sz, c_f, c_f]
         L.orc_bm4d.argtypes = [f32p, f32p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_d, c_int,
                                c_f, c_f]
+        L.orc_bm4d_e.argtypes = L.orc_bm4d.argtypes + [c_int]
+        L.orc_bm4d_e.restype = None
         L.orc_bm4d_u16.argtypes = [u16p, u16p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_d,
                                    c_int]
         L.orc_dctq_forward.argtypes = [u16p, c_int, c_int, c_int, c_f, i32p]
@@ -65,6 +78,8 @@ def lib():
         # the CPU baseline port (oracle/exabm4d_cpu_port.c): same signatures as the oracle's
         L.cpu_blockmatch.argtypes = L.orc_blockmatch.argtypes
         L.cpu_stage.argtypes = L.orc_stage.argtypes
+        L.cpu_stage_q.argtypes = L.orc_stage_q.argtypes
+        L.cpu_stage_q.restype = None
         L.cpu_bm4d.argtypes = L.orc_bm4d.argtypes
         L.cpu_bm4d_u16.argtypes = L.orc_bm4d_u16.argtypes
         for name in ("cpu_blockmatch", "cpu_stage", "cpu_bm4d", "cpu_bm4d_u16"):
@@ -132,9 +147,26 @@ def group_transform(g, inverse=False, port=False):
     return g
 
 
+AUTO_EXP = -2 ** 31      # data_exp: take E from the noisy volume (the fp32 entry points' rule)
+U16_DATA_EXP = 17        # E of the uint16 entry points
+
+
+def data_exp(vol):
+    """E with max |v| < 2^E, from the largest |v| bit pattern."""
+    vol = _f32(vol)
+    return int(lib().orc_data_exp(_p(vol, ctypes.c_float), vol.size))
+
+
+def rcp_nr(d):
+    """R(d) of DESIGN.md 3.7 for one fp32 value."""
+    return float(lib().orc_rcp_nr(float(d)))
+
+
 def stage(noisy, keys, sigma, basic=None, lambda_ht=DEFAULTS["lambda_ht"],
-          beta=DEFAULTS["kaiser_beta"], port=False):
-    """-> (num, den) of one collaborative-filtering stage (hard-threshold if basic is None)."""
+          beta=DEFAULTS["kaiser_beta"], port=False, data_exp=None):
+    """-> (num, den) of one collaborative-filtering stage (hard-threshold if basic is None):
+    num = fl32(NUM 2^(E-43)), den = corner weights (*) window.  ``data_exp`` None:
+    E from ``noisy``."""
     noisy = _f32(noisy)
     nz, ny, nx = noisy.shape
     keys = np.ascontiguousarray(keys, dtype=np.uint32)
@@ -146,8 +178,28 @@ def stage(noisy, keys, sigma, basic=None, lambda_ht=DEFAULTS["lambda_ht"],
         bp = _p(basic, ctypes.c_float)
     fn = lib().cpu_stage if port else lib().orc_stage
     fn(_p(noisy, ctypes.c_float), bp, _p(keys, ctypes.c_uint32), nz, ny, nx, float(sigma),
-       float(lambda_ht), float(beta), _p(num, ctypes.c_float), _p(den, ctypes.c_float))
+       float(lambda_ht), float(beta), AUTO_EXP if data_exp is None else int(data_exp),
+       _p(num, ctypes.c_float), _p(den, ctypes.c_float))
     return num, den
+
+
+def stage_q(noisy, keys, sigma, data_exp, basic=None, lambda_ht=DEFAULTS["lambda_ht"],
+            beta=DEFAULTS["kaiser_beta"], port=False):
+    """-> (NUM, CW): the integer sums of DESIGN.md 3.8 (numerator in units of 2^(E-43), group
+    weights on block corners in units of 2^-40)."""
+    noisy = _f32(noisy)
+    nz, ny, nx = noisy.shape
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    NUM = np.zeros(noisy.shape, dtype=np.int64)
+    CW = np.zeros(noisy.shape, dtype=np.int64)
+    bp = None
+    if basic is not None:
+        basic = _f32(basic)
+        bp = _p(basic, ctypes.c_float)
+    fn = lib().cpu_stage_q if port else lib().orc_stage_q
+    fn(_p(noisy, ctypes.c_float), bp, _p(keys, ctypes.c_uint32), nz, ny, nx, float(sigma),
+       float(lambda_ht), float(beta), int(data_exp), _p(NUM, ctypes.c_int64), _p(CW, ctypes.c_int64))
+    return NUM, CW
 
 
 def normalize(num, den, clip=None):
@@ -159,16 +211,18 @@ def normalize(num, den, clip=None):
     return out
 
 
-def bm4d(vol, sigma, stages=2, clip=None, **kw):
-    """Whole two-stage pipeline on one fp32 volume."""
+def bm4d(vol, sigma, stages=2, clip=None, data_exp=None, **kw):
+    """Whole two-stage pipeline on one fp32 volume.  ``data_exp``: E of DESIGN.md 3.8 (None: from the
+    volume, as the fp32 entry points do; 17 reproduces the uint16 entry points)."""
     p = {**DEFAULTS, **kw}
     vol = _f32(vol)
     nz, ny, nx = vol.shape
     out = np.empty_like(vol)
     lo, hi = (1.0, 0.0) if clip is None else clip
-    lib().orc_bm4d(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), nz, ny, nx, float(sigma),
-                   float(p["lambda_ht"]), float(p["c_match_ht"]), float(p["c_match_wie"]),
-                   float(p["kaiser_beta"]), int(stages), float(lo), float(hi))
+    lib().orc_bm4d_e(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), nz, ny, nx, float(sigma),
+                     float(p["lambda_ht"]), float(p["c_match_ht"]), float(p["c_match_wie"]),
+                     float(p["kaiser_beta"]), int(stages), float(lo), float(hi),
+                     AUTO_EXP if data_exp is None else int(data_exp))
     return out
 
 

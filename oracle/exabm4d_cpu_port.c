@@ -15,8 +15,9 @@
  *   - the collaborative filtering scatters in parallel: reference positions are coloured by
  *     (iz mod 5, iy mod 5) -- blocks of groups five grid steps apart cannot overlap -- and the
  *     25 colours run one after the other, every colour fully parallel.
- * Match tables are bit-identical to the oracle's (same fmaf chains, same tree, same keys);
- * estimates differ by the order of the aggregation sums (tests/test_oracle_bm4d.py compares both).
+ * Match tables are bit-identical to the oracle's (same fmaf chains, same tree, same keys), and since
+ * round 4 -- the aggregation sums are integers, DESIGN.md 3.8 -- so is everything else
+ * (tests/test_oracle_bm4d.py compares both bit for bit).
  */
 #include <math.h>
 #include <stddef.h>
@@ -43,6 +44,20 @@ void orc_group_fwd(const float* D, float* g, int K);
 void orc_group_inv(const float* D, float* g, int K);
 void orc_gather_block(const float* vol, size_t sy, size_t sz, int z, int y, int x, float* dst);
 void orc_normalize(const float* num, const float* den, float* out, size_t n, float clip_lo, float clip_hi);
+float orc_rcp_nr(float d);
+float orc_weight_ht(int nnz);
+float orc_weight_wiener(uint64_t q);
+int orc_data_exp(const float* vol, size_t n);
+void orc_den_from_corners(const int64_t* CW, int nz, int ny, int nx, double beta, float* den);
+void orc_num_to_float(const int64_t* NUM, size_t n, int data_exp, float* num);
+#define NUM_FRAC 43
+#define CW_FRAC 40
+#define RINT_MAGIC 6755399441055744.0
+static inline int64_t magic_bits(double m) {
+    int64_t b;
+    memcpy(&b, &m, 8);
+    return b - 0x4338000000000000LL;
+}
 
 static inline uint32_t f2u(float f) {
     uint32_t u;
@@ -316,10 +331,10 @@ void cpu_group_transform(float* g, int K, int inverse) {
         port_group_fwd(D, g, K);
 }
 
-/* one group: transform, shrink, inverse, scatter (same arithmetic as orc_stage) */
+/* one group: transform, shrink, inverse, scatter (same arithmetic as orc_stage_q: DESIGN.md 3.6-3.8) */
 static void one_group(const float* noisy, const float* basic, const uint32_t* kk, int rz, int ry, int rx,
                       size_t sy, size_t sz, const float* D, const float* win, float thr, float sigma2,
-                      float* num, float* den) {
+                      double up, int64_t* NUM, int64_t* CW) {
     int count = 0;
     while (count < MAXG && kk[count] != KEY_EMPTY) count++;
     int K = 1;
@@ -341,38 +356,52 @@ static void one_group(const float* noisy, const float* basic, const uint32_t* kk
             else
                 g[i] = 0.0f;
         }
-        w = 1.0f / (sigma2 * (float)(nnz > 1 ? nnz : 1));
+        w = orc_weight_ht(nnz);
     } else {
         port_group_fwd(D, gb, K);
-        float sw = 0.0f;
+        uint64_t q = 0;
         for (int i = 0; i < K * BVOX; i++) {
             const float e = gb[i] * gb[i];
-            const float W = e / (e + sigma2);
+            const float d = e + sigma2;
+            /* R(d) of DESIGN.md 3.7, inline so that the loop vectorises */
+            uint32_t rb;
+            memcpy(&rb, &d, 4);
+            rb = 0x7EF311C7u - rb;
+            float r;
+            memcpy(&r, &rb, 4);
+            for (int it = 0; it < 3; it++) {
+                const float t = fmaf(-d, r, 1.0f);
+                r = fmaf(t, r, r);
+            }
+            const float W = e * r;
             g[i] = W * g[i];
-            sw += W * W;
+            const float t1 = fmaf(W, W, 1.0f);
+            uint32_t qb;
+            memcpy(&qb, &t1, 4);
+            q += qb - 0x3F800000u;
         }
-        w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
+        w = orc_weight_wiener(q);
     }
     port_group_inv(D, g, K);
+    const int64_t U = magic_bits(fma((double)w, ldexp(1.0, CW_FRAC), RINT_MAGIC));
     for (int k = 0; k < K; k++) {
         const size_t base = (size_t)(rz + dz[k]) * sz + (size_t)(ry + dy[k]) * sy + (size_t)(rx + dx[k]);
+        CW[base] += U;
         for (int bz = 0; bz < 8; bz++)
             for (int by = 0; by < 8; by++) {
-                float* pn = num + base + bz * sz + by * sy;
-                float* pd = den + base + bz * sz + by * sy;
+                int64_t* pn = NUM + base + bz * sz + by * sy;
                 const float* e = g + (size_t)k * BVOX + (bz * 8 + by) * 8;
                 const float* wn = win + (bz * 8 + by) * 8;
                 for (int bx = 0; bx < 8; bx++) {
                     const float ww = w * wn[bx];
-                    pn[bx] += ww * e[bx];
-                    pd[bx] += ww;
+                    pn[bx] += magic_bits(fma((double)e[bx], (double)ww * up, RINT_MAGIC));
                 }
             }
     }
 }
 
-void cpu_stage(const float* noisy, const float* basic, const uint32_t* keys, int nz, int ny, int nx,
-               float sigma, float lambda_ht, double beta, float* num, float* den) {
+void cpu_stage_q(const float* noisy, const float* basic, const uint32_t* keys, int nz, int ny, int nx,
+                 float sigma, float lambda_ht, double beta, int data_exp, int64_t* NUM, int64_t* CW) {
     const int gz = orc_grid_count(nz), gy = orc_grid_count(ny), gx = orc_grid_count(nx);
     int32_t* pz = malloc(sizeof(int32_t) * (size_t)gz);
     int32_t* py = malloc(sizeof(int32_t) * (size_t)gy);
@@ -385,9 +414,11 @@ void cpu_stage(const float* noisy, const float* basic, const uint32_t* keys, int
     const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
     const float thr = (float)((double)lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
+    const double up = ldexp(1.0, NUM_FRAC - data_exp);
     /* blocks of a group reach 5 voxels in front of and 12 behind the reference corner: references
      * five grid steps (>= 17 voxels; the clamped last position is closer, so it gets a colour of
-     * its own) apart in z or in y never touch the same voxel */
+     * its own) apart in z or in y never touch the same voxel.  (The sums are integers, so the
+     * colouring only keeps the threads off each other's voxels; it no longer fixes an order.) */
     const int CZ = 6, CY = 6;
     for (int cz = 0; cz < CZ; cz++)
         for (int cy = 0; cy < CY; cy++) {
@@ -399,7 +430,7 @@ void cpu_stage(const float* noisy, const float* basic, const uint32_t* keys, int
                     if (colz != cz || coly != cy) continue;
                     for (int ix = 0; ix < gx; ix++)
                         one_group(noisy, basic, keys + ((size_t)((size_t)iz * gy + iy) * gx + ix) * MAXG, pz[iz],
-                                  py[iy], px[ix], sy, sz, D, win, thr, sigma2, num, den);
+                                  py[iy], px[ix], sy, sz, D, win, thr, sigma2, up, NUM, CW);
                 }
         }
     free(pz);
@@ -407,30 +438,49 @@ void cpu_stage(const float* noisy, const float* basic, const uint32_t* keys, int
     free(px);
 }
 
-void cpu_bm4d(const float* in, float* out, int nz, int ny, int nx, float sigma, float lambda_ht,
-              float c_match_ht, float c_match_wie, double beta, int stages, float clip_lo, float clip_hi) {
+/* the staged form: num = fl32(NUM 2^(E - 43)), den = C (*) window, both written (like orc_stage) */
+void cpu_stage(const float* noisy, const float* basic, const uint32_t* keys, int nz, int ny, int nx,
+               float sigma, float lambda_ht, double beta, int data_exp, float* num, float* den) {
+    const size_t n = (size_t)nz * ny * nx;
+    if (data_exp == INT32_MIN) data_exp = orc_data_exp(noisy, n);
+    int64_t* NUM = calloc(n, sizeof(int64_t));
+    int64_t* CW = calloc(n, sizeof(int64_t));
+    cpu_stage_q(noisy, basic, keys, nz, ny, nx, sigma, lambda_ht, beta, data_exp, NUM, CW);
+    orc_num_to_float(NUM, n, data_exp, num);
+    orc_den_from_corners(CW, nz, ny, nx, beta, den);
+    free(NUM);
+    free(CW);
+}
+
+static void cpu_bm4d_e(const float* in, float* out, int nz, int ny, int nx, float sigma, float lambda_ht,
+                       float c_match_ht, float c_match_wie, double beta, int stages, float clip_lo,
+                       float clip_hi, int data_exp) {
     const size_t n = (size_t)nz * ny * nx;
     const long nref = (long)orc_grid_count(nz) * orc_grid_count(ny) * orc_grid_count(nx);
     uint32_t* keys = malloc(sizeof(uint32_t) * (size_t)nref * MAXG);
-    float* num = calloc(n, sizeof(float));
-    float* den = calloc(n, sizeof(float));
+    float* num = malloc(n * sizeof(float));
+    float* den = malloc(n * sizeof(float));
+    if (data_exp == INT32_MIN) data_exp = orc_data_exp(in, n);
     cpu_blockmatch(in, nz, ny, nx, sigma, c_match_ht, keys);
-    cpu_stage(in, NULL, keys, nz, ny, nx, sigma, lambda_ht, beta, num, den);
+    cpu_stage(in, NULL, keys, nz, ny, nx, sigma, lambda_ht, beta, data_exp, num, den);
     if (stages < 2) {
         orc_normalize(num, den, out, n, clip_lo, clip_hi);
     } else {
         float* basic = malloc(sizeof(float) * n);
         orc_normalize(num, den, basic, n, 1.0f, 0.0f);
-        memset(num, 0, n * sizeof(float));
-        memset(den, 0, n * sizeof(float));
         cpu_blockmatch(basic, nz, ny, nx, sigma, c_match_wie, keys);
-        cpu_stage(in, basic, keys, nz, ny, nx, sigma, lambda_ht, beta, num, den);
+        cpu_stage(in, basic, keys, nz, ny, nx, sigma, lambda_ht, beta, data_exp, num, den);
         orc_normalize(num, den, out, n, clip_lo, clip_hi);
         free(basic);
     }
     free(keys);
     free(num);
     free(den);
+}
+void cpu_bm4d(const float* in, float* out, int nz, int ny, int nx, float sigma, float lambda_ht,
+              float c_match_ht, float c_match_wie, double beta, int stages, float clip_lo, float clip_hi) {
+    cpu_bm4d_e(in, out, nz, ny, nx, sigma, lambda_ht, c_match_ht, c_match_wie, beta, stages, clip_lo, clip_hi,
+               INT32_MIN);
 }
 
 void cpu_bm4d_u16(const uint16_t* in, uint16_t* out, int nz, int ny, int nx, float sigma, float offset,
@@ -440,7 +490,7 @@ void cpu_bm4d_u16(const uint16_t* in, uint16_t* out, int nz, int ny, int nx, flo
     float* g = malloc(sizeof(float) * n);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) f[i] = (float)in[i] - offset;
-    cpu_bm4d(f, g, nz, ny, nx, sigma, lambda_ht, c_match_ht, c_match_wie, beta, stages, 1.0f, 0.0f);
+    cpu_bm4d_e(f, g, nz, ny, nx, sigma, lambda_ht, c_match_ht, c_match_wie, beta, stages, 1.0f, 0.0f, 17);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         float v = g[i] + offset;

@@ -150,12 +150,12 @@ def stage(noisy, keys, sigma, basic=None, lam=2.7, beta=2.0):
                 if basic is None:
                     keep = np.abs(Z) >= thr
                     Z = Z * keep
-                    w = 1.0 / (s2 * max(int(keep.sum()), 1))
+                    w = 1.0 / max(int(keep.sum()), 1)
                 else:
                     Y = spectrum(np.asarray(basic, dtype=np.float64))
                     W = Y * Y / (Y * Y + s2)
                     Z = W * Z
-                    w = 1.0 / (s2 * max(float((W * W).sum()), 1.0))
+                    w = 1.0 / max(float((W * W).sum()), 1.0)
                 est = np.einsum("kj,ua,vb,wc,kuvw->jabc", H, D, D, D, Z)
                 for j, (dz, dy, dx) in enumerate(disp):
                     sl = (slice(rz + dz, rz + dz + 8), slice(ry + dy, ry + dy + 8), slice(rx + dx, rx + dx + 8))

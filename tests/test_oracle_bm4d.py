@@ -120,7 +120,8 @@ def test_psnr_gain_and_stage_order(oracle):
 
 def test_u16_pipeline_equals_float_pipeline(oracle):
     vol, _ = synth_volume((24, 28, 32), seed=8, as_u16=True)
-    f = oracle.bm4d(vol.astype(np.float32) - np.float32(37.0), SIGMA)
+    # the uint16 form fixes the numerator's unit (E = 17) instead of reading it off the data
+    f = oracle.bm4d(vol.astype(np.float32) - np.float32(37.0), SIGMA, data_exp=oracle.U16_DATA_EXP)
     want = np.rint(np.clip(f + np.float32(37.0), 0, 65535)).astype(np.uint16)
     np.testing.assert_array_equal(oracle.bm4d_u16(vol, SIGMA, 37.0), want)
 
@@ -188,8 +189,9 @@ def test_aggregation_denominator_is_a_convolution(oracle):
 def test_cpu_port_equals_the_oracle(oracle):
     """oracle/exabm4d_cpu_port.c (bench.py's cpu_baseline: shared cell sums, SIMD over dx and over
     transform lines, coloured parallel scatter) against the checker: match tables and 4-D
-    transforms bit-identical, stage sums to fp32 summation order, uint16 results within one count --
-    on aligned and ragged extents, one thread and several."""
+    transforms bit-identical and -- the aggregation sums being integers since round 4, DESIGN.md 3.8 -- the
+    stage sums, the normalised estimates and the uint16 results too, whatever the order the port's
+    threads add in -- on aligned and ragged extents, one thread and several."""
     rng = np.random.default_rng(7)
     for K in (1, 2, 4, 8, 16):
         g = rng.normal(0, 300, (K, 8, 8, 8)).astype(np.float32)
@@ -204,21 +206,110 @@ def test_cpu_port_equals_the_oracle(oracle):
             keys = oracle.blockmatch(vol, 24.0, c_match)
             np.testing.assert_array_equal(oracle.blockmatch(vol, 24.0, c_match, port=True), keys)
         keys = oracle.blockmatch(vol, 24.0)
+        E = oracle.data_exp(vol)
+        NUM, CW = oracle.stage_q(vol, keys, 24.0, E)
+        PN, PC = oracle.stage_q(vol, keys, 24.0, E, port=True)
+        np.testing.assert_array_equal(PN, NUM)
+        np.testing.assert_array_equal(PC, CW)
         num, den = oracle.stage(vol, keys, 24.0)
         pn, pd = oracle.stage(vol, keys, 24.0, port=True)
-        np.testing.assert_allclose(pn, num, rtol=2e-5, atol=1e-6 * float(np.abs(num).max()))
-        np.testing.assert_allclose(pd, den, rtol=2e-5)
+        np.testing.assert_array_equal(pn, num)
+        np.testing.assert_array_equal(pd, den)
         basic = oracle.normalize(num, den)
         wn, wd = oracle.stage(vol, keys, 24.0, basic=basic)
         qn, qd = oracle.stage(vol, keys, 24.0, basic=basic, port=True)
-        np.testing.assert_allclose(qn, wn, rtol=2e-5, atol=1e-6 * float(np.abs(wn).max()))
-        np.testing.assert_allclose(qd, wd, rtol=2e-5)
+        np.testing.assert_array_equal(qn, wn)
+        np.testing.assert_array_equal(qd, wd)
     oracle.set_threads(len(os.sched_getaffinity(0)))
     u16, _ = synth_volume((40, 36, 44), seed=3, as_u16=True)
     a = oracle.bm4d_u16(u16, 24.0, 37.0)
     b = oracle.bm4d_u16(u16, 24.0, 37.0, port=True)
-    d = np.abs(a.astype(np.int32) - b.astype(np.int32))
-    assert d.max() <= 1 and np.mean(d > 0) < 1e-3
+    np.testing.assert_array_equal(a, b)
+    oracle.set_threads(1)                      # ... and the thread count does not matter either
+    np.testing.assert_array_equal(oracle.bm4d_u16(u16, 24.0, 37.0, port=True), b)
+    oracle.set_threads(len(os.sched_getaffinity(0)))
+
+
+# ---- round 4: the order-independent aggregation ---------------------------------------------
+def test_wiener_reciprocal_is_within_an_ulp_and_bit_defined(oracle):
+    """R(d) (3.7): integer-subtraction seed + three fused Newton steps -- restated here with numpy's
+    IEEE float32 / float64 operations, bit for bit, and within 1.5 ulp of 1/d over 60 binades."""
+    rng = np.random.default_rng(11)
+    d = np.exp2(rng.uniform(-30, 30, 4000)).astype(np.float32)
+    d[:4] = np.float32([1.0, 576.0, 2.0 ** -20, 3.0e9])
+    r = (np.uint32(0x7EF311C7) - d.view(np.uint32)).view(np.float32)
+    for _ in range(3):
+        # fma(a, b, c) of float32 operands = float32(exact a*b + c): a*b is exact in float64 and the sum of
+        # a 48-bit product and a 24-bit addend rounds once in float64 only beyond 2^-53 -- far below float32
+        t = (np.float64(1.0) - d.astype(np.float64) * r.astype(np.float64)).astype(np.float32)
+        r = (t.astype(np.float64) * r.astype(np.float64) + r.astype(np.float64)).astype(np.float32)
+    got = np.array([oracle.rcp_nr(x) for x in d], dtype=np.float32)
+    np.testing.assert_array_equal(got, r)
+    exact = 1.0 / d.astype(np.float64)
+    assert np.max(np.abs(got.astype(np.float64) - exact) / np.spacing(exact.astype(np.float32)).astype(np.float64)) < 1.5
+
+
+def test_data_exponent_rule(oracle):
+    """3.8: E = the exponent with max |v| < 2^E, read off the largest |v| bit pattern."""
+    for v, E in ((1.0, 1), (0.99, 0), (65535.0, 16), (65536.0, 17), (-3000.0, 12), (1e-3, -9), (0.0, -126)):
+        vol = np.zeros((8, 8, 8), np.float32)
+        vol[3, 4, 5] = v
+        assert oracle.data_exp(vol) == E, (v, E)
+        assert abs(v) < 2.0 ** E
+
+
+def test_integer_sums_follow_their_definition(oracle):
+    """3.8 restated in float64 / Python integers for a handful of groups: NUM = sum of
+    rint(est * fl32(u * win) * 2^(43 - E)) (half-to-even), CW = sum of rint(u * 2^40) on block corners, and
+    the staged outputs num = fl32(fl64(NUM) 2^(E - 43)), den = the three 8-tap fp32 passes over fl32(CW 2^-40)."""
+    vol, _ = synth_volume((16, 12, 20), seed=21)
+    keys = oracle.blockmatch(vol, SIGMA, 3.0)
+    E = oracle.data_exp(vol)
+    NUM, CW = oracle.stage_q(vol, keys, SIGMA, E)
+    _, win = oracle.tables()
+    win = np.asarray(win, np.float32).reshape(8, 8, 8)
+    thr = np.float32(np.float64(np.float32(2.7)) * np.float64(np.float32(SIGMA)))
+    want_num = np.zeros(vol.shape, dtype=object)
+    want_cw = np.zeros(vol.shape, dtype=object)
+    want_num[...] = 0
+    want_cw[...] = 0
+    pz, py, px = (oracle.grid_positions(n) for n in vol.shape)
+    for iz, rz in enumerate(pz):
+        for iy, ry in enumerate(py):
+            for ix, rx in enumerate(px):
+                disp = [d for d, _ in oracle.decode_keys(keys[iz, iy, ix])]
+                K = 1
+                while K * 2 <= len(disp):
+                    K *= 2
+                disp = disp[:K]
+                g = np.stack([vol[rz + a:rz + a + 8, ry + b:ry + b + 8, rx + c:rx + c + 8] for a, b, c in disp])
+                spec = oracle.group_transform(g)
+                keep = np.abs(spec) >= thr
+                u = np.float32(1.0) / np.float32(max(int(keep.sum()), 1))
+                est = oracle.group_transform(np.where(keep, spec, np.float32(0)), inverse=True)
+                U = int(np.rint(np.float64(u) * 2.0 ** 40))
+                ww = (u * win).astype(np.float32)
+                terms = np.rint(est.astype(np.float64) * ww.astype(np.float64)[None] * 2.0 ** (43 - E))
+                for j, (a, b, c) in enumerate(disp):
+                    want_cw[rz + a, ry + b, rx + c] += U
+                    sl = (slice(rz + a, rz + a + 8), slice(ry + b, ry + b + 8), slice(rx + c, rx + c + 8))
+                    want_num[sl] += terms[j].astype(np.int64).astype(object)
+    np.testing.assert_array_equal(NUM, want_num.astype(np.int64))
+    np.testing.assert_array_equal(CW, want_cw.astype(np.int64))
+    num, den = oracle.stage(vol, keys, SIGMA)
+    np.testing.assert_array_equal(num, (NUM.astype(np.float64) * 2.0 ** (E - 43)).astype(np.float32))
+    k = np.kaiser(8, 2.0).astype(np.float32)
+    out = (CW.astype(np.float64) * 2.0 ** -40).astype(np.float32)
+    for axis in (2, 1, 0):
+        acc = np.zeros_like(out)
+        for t in range(8):                     # acc = fma(k[t], in(i - t), acc), t ascending, from +0
+            dst = [slice(None)] * 3
+            src = [slice(None)] * 3
+            dst[axis] = slice(t, None)
+            src[axis] = slice(0, out.shape[axis] - t)
+            acc[tuple(dst)] = (np.float64(k[t]) * out[tuple(src)].astype(np.float64) + acc[tuple(dst)].astype(np.float64)).astype(np.float32)
+        out = acc
+    np.testing.assert_array_equal(den, out)
 
 
 # ---- the C oracle against an independent numpy reading of DESIGN.md section 3 (tests/bm4d_pyref.py) ----------
