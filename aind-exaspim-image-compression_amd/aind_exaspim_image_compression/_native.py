@@ -27,6 +27,8 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 c_vp = ctypes.c_void_p
 
 KEY_EMPTY = 0xFFFFFFFF
+DATA_EXP_AUTO = -2 ** 31    # exabm4d.h EXABM4D_DATA_EXP_AUTO: E per volume from the data (fp32 entry points)
+DATA_EXP_U16 = 17           # exabm4d.h EXABM4D_DATA_EXP_U16: the uint16 pipelines' fixed E
 
 
 class Params(ctypes.Structure):
@@ -101,7 +103,7 @@ SIGNATURES = {
     "exabm4d_blockmatch_u16_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _F, _F, _PP, c_vp]),
     "exabm4d_match_decode": (_I, [c_u32p, _I, _I, _I, _I, _I, c_i64p, c_f32p,
                                   ctypes.POINTER(_I)]),
-    "exabm4d_stage_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, c_vp, c_vp]),
+    "exabm4d_stage_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, c_vp, c_vp]),
     "exabm4d_normalize_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F, _F]),
     "exabm4d_counts_from_u16_dev": (_I, [_CTX, c_vp, c_vp, _SZ, _F]),
     "exabm4d_normalize_u16_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F]),
@@ -268,7 +270,10 @@ class DeviceBuffer:
         return out
 
     def zero(self):
-        self.ctx._check(lib().exabm4d_memset(self.ctx.handle, self.ptr, 0, self.nbytes))
+        return self.fill(0)
+
+    def fill(self, byte):
+        self.ctx._check(lib().exabm4d_memset(self.ctx.handle, self.ptr, int(byte), self.nbytes))
         return self
 
     def free(self):
@@ -366,11 +371,15 @@ class Context:
                                                      float(sigma), float(c_match), ctypes.byref(p),
                                                      _ptr(keys)))
 
-    def stage(self, noisy, basic, keys, shape, sigma, num, den, params=None, batch=1):
+    def stage(self, noisy, basic, keys, shape, sigma, num, den, params=None, batch=1, data_exp=None):
+        """One collaborative-filtering stage; ``num`` / ``den`` (fp32) are WRITTEN.  ``data_exp``: E of
+        the numerator's fixed-point unit; None = per volume from ``noisy`` (the fp32
+        pipelines' rule), DATA_EXP_U16 = what the uint16 pipelines use."""
         p = params or default_params()
         nz, ny, nx = shape
         self._check(lib().exabm4d_stage_dev(self.handle, _ptr(noisy), _ptr(basic), _ptr(keys), nz,
                                             ny, nx, batch, float(sigma), ctypes.byref(p),
+                                            DATA_EXP_AUTO if data_exp is None else int(data_exp),
                                             _ptr(num), _ptr(den)))
 
     def normalize(self, num, den, out, n, clip=None):

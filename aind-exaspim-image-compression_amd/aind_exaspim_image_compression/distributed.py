@@ -160,18 +160,36 @@ def denoise_slab_u16(raw, plan, offset, denoiser, dist=None, group=None):
     return denoiser.stage2_u16(noisy, basic, offset)[plan.core]
 
 
+def global_data_exp(noisy, dist=None, group=None):
+    """E with max |v| < 2^E over the WHOLE sharded fp32 volume: the exponent of this
+    rank's largest |v| bit pattern, MAX-reduced over the ranks (one int; the only collective the exact
+    slab mode adds to its halo exchange).  ``noisy``: this rank's planes as a torch tensor."""
+    import torch
+    bits = int(noisy.detach().abs().max().view(torch.int32).item()) if noisy.numel() else 0
+    e = torch.tensor([(bits >> 23) - 126], dtype=torch.int32, device=noisy.device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(e, op=dist.ReduceOp.MAX, group=group)
+    return int(e.item())
+
+
 class SlabDenoiser:
     """The two stage callables of ``denoise_slab`` on one MI355X, through the staged C-ABI entry
     points (exabm4d_blockmatch_dev / exabm4d_stage_dev / exabm4d_normalize_dev), with all
     scratch held as torch tensors on the rank's device."""
 
-    def __init__(self, shape, sigma, device, params=None):
+    def __init__(self, shape, sigma, device, params=None, data_exp=None):
+        """``data_exp``: E of the numerator's fixed-point unit for the fp32 callables
+        ``stage1`` / ``stage2``.  The single-GPU fp32 pipeline reads E off the whole volume; a sharded run
+        that wants the same bits passes the same E to every rank (``global_data_exp``).  None: from this
+        rank's slab.  The uint16 callables always use the uint16 pipelines' E = 17."""
         import torch
         from aind_exaspim_image_compression import _native
         self.torch = torch
         self.shape = tuple(int(s) for s in shape)
         self.sigma = float(sigma)
         self.params = params or _native.default_params()
+        self.data_exp = data_exp
+        self.u16_exp = _native.DATA_EXP_U16
         self.device = torch.device(device)
         self.ctx = _native.context(self.device.index or 0)
         g = [len(_native.grid_positions(n)) for n in self.shape]
@@ -185,11 +203,9 @@ class SlabDenoiser:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
             ctx.set_stream(stream.cuda_stream)
-            self.num.zero_()
-            self.den.zero_()
             ctx.blockmatch(match_on, self.shape, self.sigma, c_match, self.keys, self.params)
             ctx.stage(noisy, basic, self.keys, self.shape, self.sigma, self.num, self.den,
-                      self.params)
+                      self.params, data_exp=self.data_exp)
             out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
             ctx.normalize(self.num, self.den, out, n)
             stream.synchronize()
@@ -215,15 +231,14 @@ class SlabDenoiser:
             noisy = torch.empty(self.shape, dtype=torch.float32, device=self.device)
             basic = torch.empty(self.shape, dtype=torch.float32, device=self.device)
             ctx.counts_from_u16(raw, noisy, n, float(offset))
-            self.num.zero_()
-            self.den.zero_()
             if offset_exact_in_fp32(offset):
                 ctx.blockmatch_u16(raw, self.shape, self.sigma, self.params.c_match_ht, self.keys,
                                    self.params)
             else:                       # (float)v - offset is rounded: match on what stage 1 filters
                 ctx.blockmatch(noisy, self.shape, self.sigma, self.params.c_match_ht, self.keys,
                                self.params)
-            ctx.stage(noisy, None, self.keys, self.shape, self.sigma, self.num, self.den, self.params)
+            ctx.stage(noisy, None, self.keys, self.shape, self.sigma, self.num, self.den, self.params,
+                      data_exp=self.u16_exp)
             ctx.normalize(self.num, self.den, basic, n)
             stream.synchronize()
             ctx.reset_stream()
@@ -237,11 +252,10 @@ class SlabDenoiser:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
             ctx.set_stream(stream.cuda_stream)
-            self.num.zero_()
-            self.den.zero_()
             ctx.blockmatch(basic, self.shape, self.sigma, self.params.c_match_wie, self.keys,
                            self.params)
-            ctx.stage(noisy, basic, self.keys, self.shape, self.sigma, self.num, self.den, self.params)
+            ctx.stage(noisy, basic, self.keys, self.shape, self.sigma, self.num, self.den, self.params,
+                      data_exp=self.u16_exp)
             out = torch.empty(self.shape, dtype=torch.int16, device=self.device)
             ctx.normalize_u16(self.num, self.den, out, n, float(offset))
             stream.synchronize()

@@ -409,19 +409,30 @@ hipError_t launch_chunk_scatter(const float* est, const ChunkBatch& cb, float of
     return hipGetLastError();
 }
 
-// ---- denominator of the aggregation as a convolution (stage_kernels.hip, two-waves-per-group) ----
-// out(i) = sum_{t=0..7} k[t] * in(i - t) along one axis: a block corner c with weight w spreads
-// w * k[t] over voxels c .. c + 7.  Fixed summation order, so the result is deterministic.
+// ---- denominator of the aggregation as a convolution (stage_kernels.hip) -------------------------
+// The stage kernels leave sum(rint(u 2^40)) of the blocks on their corner voxels (64-bit integers, exact
+// whatever the order of the atomics).  C = fl32(cw 2^-40); out(i) = sum_{t=0..7} k[t] * in(i - t) along
+// one axis: a block corner c with weight u spreads u * k[t] over voxels c .. c + 7.  Fixed summation
+// order (fmaf chain, t ascending, from +0): DESIGN.md 3.8, oracle orc_den_from_corners.
 struct Win1D {
     float k[8];
 };
+__device__ __forceinline__ float cw_to_float(unsigned long long c) {
+    // c < 2^53 (at most 2^12 blocks of at most 2^40 per corner): both conversions and the scaling are
+    // exact, the cast to float rounds once
+    return (float)(((double)(unsigned)(c >> 32) * 4294967296.0 + (double)(unsigned)c) * 9.094947017729282e-13);
+}
+// int64 fixed point -> fp32: fl64(num) (one rounding beyond 2^53), exact scaling, one rounding to fp32
+__device__ __forceinline__ float num_to_float(long long v, double down) {
+    return (float)(__ll2double_rn(v) * down);
+}
 // along y or z: one thread per line (lanes along x: coalesced), marching with the last 8 inputs
 // in registers, so every input is read once.  Line (o, i): base = o * extent * inner + i,
 // element stride `inner`.
-// With XFIRST the value fed into the line is itself the 8-tap convolution along x of the input
-// row (8 neighbouring loads, L1 hits), which fuses the x and y passes.
-template <bool ACCUMULATE, bool XFIRST>
-__global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __restrict__ in,
+// With XFIRST the input is the corner-weight volume and the value fed into the line is the 8-tap
+// convolution along x of its row (8 neighbouring loads, L1 hits), which fuses the x and y passes.
+template <bool XFIRST>
+__global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const void* __restrict__ in_,
                                                                 float* __restrict__ out, size_t nlines,
                                                                 size_t inner, int extent, Win1D w) {
     for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
@@ -436,33 +447,31 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_line_kernel(const float* __r
             for (int t = 7; t > 0; t--) h[t] = h[t - 1];
             if (XFIRST) {
                 // lines run along y, `inner` is the row length and i the x coordinate
-                const float* row = in + base + (size_t)e * inner;
+                const unsigned long long* row = static_cast<const unsigned long long*>(in_) + base + (size_t)e * inner;
                 float ax = 0.0f;
 #pragma unroll
                 for (int t = 0; t < 8; t++)
-                    if ((size_t)t <= i) ax = fmaf(w.k[t], *(row - t), ax);
+                    if ((size_t)t <= i) ax = fmaf(w.k[t], cw_to_float(*(row - t)), ax);
                 h[0] = ax;
             } else {
-                h[0] = in[base + (size_t)e * inner];
+                h[0] = static_cast<const float*>(in_)[base + (size_t)e * inner];
             }
             float acc = 0.0f;
 #pragma unroll
             for (int t = 0; t < 8; t++) acc = fmaf(w.k[t], h[t], acc);
-            if (ACCUMULATE)
-                out[base + (size_t)e * inner] += acc;
-            else
-                out[base + (size_t)e * inner] = acc;
+            out[base + (size_t)e * inner] = acc;
         }
     }
 }
 
 // Fused x / y pass for row lengths that are multiples of 4: one thread owns four consecutive x
-// outputs and marches along y.  Per row it loads its own float4 and the eight values to its left
-// (three 16-byte loads for four outputs instead of eight scalar loads per output), forms the four
-// x-convolutions in registers and pushes them through four 8-deep y shift registers.
-__global__ __launch_bounds__(EW_THREADS) void conv8_xy4_kernel(const float* __restrict__ in,
+// outputs and marches along y.  Per row it loads its own four corner weights and the eight to its left
+// (six 16-byte loads for four outputs), forms the four x-convolutions in registers and pushes them
+// through four 8-deep y shift registers.
+__global__ __launch_bounds__(EW_THREADS) void conv8_xy4_kernel(const unsigned long long* __restrict__ in,
                                                                float* __restrict__ out, size_t nlines,
                                                                int nx4, int ny, Win1D w) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
          l += (size_t)gridDim.x * EW_THREADS) {
         const size_t o = l / (size_t)nx4;              // (volume, z) index
@@ -475,11 +484,16 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_xy4_kernel(const float* __re
 #pragma unroll
             for (int j = 0; j < 4; j++) h[t][j] = 0.0f;
         for (int y = 0; y < ny; y++) {
-            const float* row = in + base + (size_t)y * nx;
-            const float4 c = *reinterpret_cast<const float4*>(row);
-            const float4 l1 = x0 >= 4 ? *reinterpret_cast<const float4*>(row - 4) : make_float4(0, 0, 0, 0);
-            const float4 l2 = x0 >= 8 ? *reinterpret_cast<const float4*>(row - 8) : make_float4(0, 0, 0, 0);
-            const float win_[12] = {l2.x, l2.y, l2.z, l2.w, l1.x, l1.y, l1.z, l1.w, c.x, c.y, c.z, c.w};
+            const unsigned long long* row = in + base + (size_t)y * nx;
+            float win_[12];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                // elements row[2 q - 8], row[2 q - 7]: left of the row start they count as zero
+                u64x2 v = {0ull, 0ull};
+                if (x0 + 2 * q - 8 >= 0) v = *reinterpret_cast<const u64x2*>(row + 2 * q - 8);
+                win_[2 * q] = cw_to_float(v.x);
+                win_[2 * q + 1] = cw_to_float(v.y);
+            }
 #pragma unroll
             for (int t = 7; t > 0; t--)
 #pragma unroll
@@ -506,11 +520,13 @@ __global__ __launch_bounds__(EW_THREADS) void conv8_xy4_kernel(const float* __re
 
 // The z pass of the denominator convolution fused into the normalisation (round 3): a thread owns W
 // consecutive x of one (volume, y) line and marches along z with the 8-deep shift register of
-// conv8_line_kernel -- den = the same fmaf chain, in the same order -- then out = num / den (+ clip,
-// or + offset, clamp, rint, uint16).  Saves the pass that wrote den and the one that read it back
-// (8 B per voxel and stage); results are bit-identical to the two-kernel form.
+// conv8_line_kernel -- den = the same fmaf chain, in the same order -- then
+// out = fl32(fl64(num) 2^(E - 43)) / den (+ clip, or + offset, clamp, rint, uint16).  Saves the pass that
+// would write den and the one that would read it back; bit-identical to the separate passes of the staged
+// entry points.
 template <int W, bool U16>
-__global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float* __restrict__ num,
+__global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const long long* __restrict__ num,
+                                                                     const double* __restrict__ qscale,
                                                                      const float* __restrict__ txy,
                                                                      void* __restrict__ out, size_t nlines,
                                                                      size_t plane, int nz, Win1D w, float lo,
@@ -519,11 +535,13 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float
                                                                      float* __restrict__ pair_out) {
     // pair_out (fp32 output, W = 4 only): additionally the interleaved volume (pair_src, out) the Wiener
     // kernel gathers from, so that it does not cost a pass of its own
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const size_t lines_per_vol = plane / W;
     for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
          l += (size_t)gridDim.x * EW_THREADS) {
         const size_t o = l / lines_per_vol, i = l - o * lines_per_vol;
         const size_t base = o * (size_t)nz * plane + (size_t)W * i;
+        const double down = qscale[2 * o + 1];
         float h[8][W];
 #pragma unroll
         for (int t = 0; t < 8; t++)
@@ -538,12 +556,14 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float
             float a[W];
             if (W == 4) {
                 const float4 c = *reinterpret_cast<const float4*>(txy + at);
-                const float4 m = *reinterpret_cast<const float4*>(num + at);
+                const i64x2 m0 = *reinterpret_cast<const i64x2*>(num + at);
+                const i64x2 m1 = *reinterpret_cast<const i64x2*>(num + at + 2);
                 h[0][0] = c.x; h[0][1 % W] = c.y; h[0][2 % W] = c.z; h[0][3 % W] = c.w;
-                a[0] = m.x; a[1 % W] = m.y; a[2 % W] = m.z; a[3 % W] = m.w;
+                a[0] = num_to_float(m0.x, down); a[1 % W] = num_to_float(m0.y, down);
+                a[2 % W] = num_to_float(m1.x, down); a[3 % W] = num_to_float(m1.y, down);
             } else {
                 h[0][0] = txy[at];
-                a[0] = num[at];
+                a[0] = num_to_float(num[at], down);
             }
             float r[W];
 #pragma unroll
@@ -583,31 +603,32 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const float
     }
 }
 
-// den's x / y passes only (C -> tmp); the z pass then rides with the normalisation (launch_normalize_zconv)
-hipError_t launch_den_xy_from_corners(float* C, float* tmp, int nz, int ny, int nx, int batch, const float* win1d,
-                                      hipStream_t s) {
+static dim3 conv_blocks(size_t items) {
+    size_t b = (items + EW_THREADS - 1) / EW_THREADS;
+    if (b > 65536) b = 65536;
+    return dim3((unsigned)(b ? b : 1));
+}
+// den's x / y passes only (cw -> tmp); the z pass then rides with the normalisation (launch_normalize_zconv)
+hipError_t launch_den_xy_from_corners(const unsigned long long* cw, float* tmp, int nz, int ny, int nx, int batch,
+                                      const float* win1d, hipStream_t s) {
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
-    auto blocks = [](size_t items) {
-        size_t b = (items + EW_THREADS - 1) / EW_THREADS;
-        if (b > 65536) b = 65536;
-        return dim3((unsigned)(b ? b : 1));
-    };
-    if (nx % 4 == 0 && ((uintptr_t)C & 15u) == 0 && ((uintptr_t)tmp & 15u) == 0) {
+    if (nx % 4 == 0 && ((uintptr_t)cw & 15u) == 0 && ((uintptr_t)tmp & 15u) == 0) {
         const size_t lines4 = (size_t)batch * nz * (nx / 4);
-        hipLaunchKernelGGL(conv8_xy4_kernel, blocks(lines4), dim3(EW_THREADS), 0, s, C, tmp, lines4, nx / 4, ny, w);
+        hipLaunchKernelGGL(conv8_xy4_kernel, conv_blocks(lines4), dim3(EW_THREADS), 0, s, cw, tmp, lines4, nx / 4, ny, w);
     } else {
         const size_t ylines = (size_t)batch * nz * nx;
-        hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp, ylines,
-                           (size_t)nx, ny, w);
+        hipLaunchKernelGGL((conv8_line_kernel<true>), conv_blocks(ylines), dim3(EW_THREADS), 0, s,
+                           static_cast<const void*>(cw), tmp, ylines, (size_t)nx, ny, w);
     }
     return hipGetLastError();
 }
 
-// out = num / (txy (*)_z win): exactly one of out_f32 / out_u16
-hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out_f32, uint16_t* out_u16, int nz,
-                                  int ny, int nx, int batch, const float* win1d, float lo, float hi, float offset,
-                                  hipStream_t s, const float* pair_src, float* pair_out, int* pair_written) {
+// out = fl32(fl64(num) 2^(E - 43)) / (txy (*)_z win): exactly one of out_f32 / out_u16
+hipError_t launch_normalize_zconv(const long long* num, const double* qscale, const float* txy, float* out_f32,
+                                  uint16_t* out_u16, int nz, int ny, int nx, int batch, const float* win1d,
+                                  float lo, float hi, float offset, hipStream_t s, const float* pair_src,
+                                  float* pair_out, int* pair_written) {
     if (pair_written) *pair_written = 0;
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
@@ -616,55 +637,91 @@ hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out
     const bool wide = plane % 4 == 0 && ((uintptr_t)num & 15u) == 0 && ((uintptr_t)txy & 15u) == 0 &&
                       ((uintptr_t)out & 15u) == 0 && ((size_t)nz * plane) % 4 == 0;
     const size_t nlines = (size_t)batch * (wide ? plane / 4 : plane);
-    size_t b = (nlines + EW_THREADS - 1) / EW_THREADS;
-    if (b > 65536) b = 65536;
-    const dim3 grid((unsigned)(b ? b : 1));
+    const dim3 grid = conv_blocks(nlines);
     const int clip = lo <= hi ? 1 : 0;
     const float* nul = nullptr;
     float* nulw = nullptr;
     if (wide && out_u16) {
-        hipLaunchKernelGGL((normalize_zconv_kernel<4, true>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines, plane,
-                           nz, w, lo, hi, clip, offset, nul, nulw);
+        hipLaunchKernelGGL((normalize_zconv_kernel<4, true>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
+                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw);
     } else if (wide) {
         const bool pw = pair_src && pair_out && ((uintptr_t)pair_src & 15u) == 0 && ((uintptr_t)pair_out & 15u) == 0;
-        hipLaunchKernelGGL((normalize_zconv_kernel<4, false>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines,
-                           plane, nz, w, lo, hi, clip, offset, pw ? pair_src : nul, pw ? pair_out : nulw);
+        hipLaunchKernelGGL((normalize_zconv_kernel<4, false>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
+                           nlines, plane, nz, w, lo, hi, clip, offset, pw ? pair_src : nul, pw ? pair_out : nulw);
         if (pair_written && pw) *pair_written = 1;
     } else if (out_u16) {
-        hipLaunchKernelGGL((normalize_zconv_kernel<1, true>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines, plane,
-                           nz, w, lo, hi, clip, offset, nul, nulw);
+        hipLaunchKernelGGL((normalize_zconv_kernel<1, true>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
+                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw);
     } else {
-        hipLaunchKernelGGL((normalize_zconv_kernel<1, false>), grid, dim3(EW_THREADS), 0, s, num, txy, out, nlines,
-                           plane, nz, w, lo, hi, clip, offset, nul, nulw);
+        hipLaunchKernelGGL((normalize_zconv_kernel<1, false>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
+                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
-                                   const float* win1d, int overwrite, hipStream_t s) {
+// the staged entry point's form: all three passes, den written
+hipError_t launch_den_from_corners(const unsigned long long* cw, float* tmp, float* den, int nz, int ny, int nx,
+                                   int batch, const float* win1d, hipStream_t s) {
+    hipError_t e = launch_den_xy_from_corners(cw, tmp, nz, ny, nx, batch, win1d, s);
+    if (e != hipSuccess) return e;
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
-    auto blocks = [](size_t items) {
-        size_t b = (items + EW_THREADS - 1) / EW_THREADS;
-        if (b > 65536) b = 65536;
-        return dim3((unsigned)(b ? b : 1));
-    };
-    // x and y fused (C -> tmp), then z (den += conv(tmp))
-    const size_t ylines = (size_t)batch * nz * nx, zlines = (size_t)batch * ny * nx;
-    if (nx % 4 == 0 && ((uintptr_t)C & 15u) == 0 && ((uintptr_t)tmp & 15u) == 0) {
-        const size_t lines4 = (size_t)batch * nz * (nx / 4);
-        hipLaunchKernelGGL(conv8_xy4_kernel, blocks(lines4), dim3(EW_THREADS), 0, s, C, tmp, lines4, nx / 4,
-                           ny, w);
-    } else {
-        hipLaunchKernelGGL((conv8_line_kernel<false, true>), blocks(ylines), dim3(EW_THREADS), 0, s, C, tmp,
-                           ylines, (size_t)nx, ny, w);
+    const size_t zlines = (size_t)batch * ny * nx;
+    hipLaunchKernelGGL((conv8_line_kernel<false>), conv_blocks(zlines), dim3(EW_THREADS), 0, s,
+                       static_cast<const void*>(tmp), den, zlines, (size_t)ny * nx, nz, w);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(EW_THREADS) void num_to_float_kernel(const long long* __restrict__ num,
+                                                                  const double* __restrict__ qscale,
+                                                                  float* __restrict__ out, size_t nvox) {
+    const double down = qscale[2 * blockIdx.y + 1];
+    const size_t off = (size_t)blockIdx.y * nvox;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvox; i += (size_t)gridDim.x * EW_THREADS)
+        out[off + i] = num_to_float(num[off + i], down);
+}
+hipError_t launch_num_to_float(const long long* num, const double* qscale, float* out, size_t nvox, int batch,
+                               hipStream_t s) {
+    size_t b = (nvox + EW_THREADS - 1) / EW_THREADS;
+    if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(num_to_float_kernel, dim3((unsigned)(b ? b : 1), (unsigned)batch), dim3(EW_THREADS), 0, s, num,
+                       qscale, out, nvox);
+    return hipGetLastError();
+}
+
+// ---- the numerator's unit -----------------------------------------------------------
+// E with max |v| < 2^E from the largest |v| bit pattern of each volume (an integer maximum: exact and
+// order-independent), then qscale[2 b] = 2^(43 - E), qscale[2 b + 1] = 2^(E - 43).
+__global__ __launch_bounds__(EW_THREADS) void absmax_bits_kernel(const float* __restrict__ vol, size_t nvox,
+                                                                 unsigned* __restrict__ maxbits) {
+    const float* v = vol + (size_t)blockIdx.y * nvox;
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nvox; i += (size_t)gridDim.x * EW_THREADS)
+        m = max(m, __float_as_uint(v[i]) & 0x7FFFFFFFu);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits + blockIdx.y, m);
+}
+__global__ void qscale_kernel(const unsigned* __restrict__ maxbits, int batch, int fixed_exp,
+                              double* __restrict__ qscale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int E = fixed_exp != INT32_MIN ? fixed_exp : (int)(maxbits[b] >> 23) - 126;
+    qscale[2 * b] = ldexp(1.0, 43 - E);
+    qscale[2 * b + 1] = ldexp(1.0, E - 43);
+}
+hipError_t launch_qscale(const float* vol, size_t nvox, int batch, int fixed_exp, unsigned* maxbits,
+                         double* qscale, hipStream_t s) {
+    if (fixed_exp == INT32_MIN) {
+        hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned) * (size_t)batch, s);
+        if (e != hipSuccess) return e;
+        size_t b = (nvox + (size_t)EW_THREADS * 8 - 1) / ((size_t)EW_THREADS * 8);
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL(absmax_bits_kernel, dim3((unsigned)(b ? b : 1), (unsigned)batch), dim3(EW_THREADS), 0, s, vol,
+                           nvox, maxbits);
     }
-    if (overwrite)
-        hipLaunchKernelGGL((conv8_line_kernel<false, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp,
-                           den, zlines, (size_t)ny * nx, nz, w);
-    else
-        hipLaunchKernelGGL((conv8_line_kernel<true, false>), blocks(zlines), dim3(EW_THREADS), 0, s, tmp,
-                           den, zlines, (size_t)ny * nx, nz, w);
+    hipLaunchKernelGGL(qscale_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s, maxbits, batch, fixed_exp,
+                       qscale);
     return hipGetLastError();
 }
 

@@ -38,11 +38,10 @@ struct exabm4d_ctx {
     size_t red_bytes = 0;
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
     int bm_guarded_copy = 0;   // exabm4d_set_option("bm_guarded_copy"): staged block matching on a guarded copy
-    int stage_pairs = 1;       // exabm4d_set_option("stage_pairs"): two waves per group (HT stage)
+    StageOpts stage;           // exabm4d_set_option("stage_pairvol" / "stage_strip" / "stage_chunks")
     int profile = 0;           // exabm4d_set_option("profile")
     int bm_int = 1;            // exabm4d_set_option("bm_int"): integer block matching on uint16 input
     int codec_version = 2;     // exabm4d_set_option("codec_version"): stream format the encoder writes
-    int fuse_den_z = 1;        // exabm4d_set_option("fuse_den_z"): z pass of the denominator inside the normalisation
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
     void* bm_carry = nullptr;  // block matching: the tiles' carried cell layers (bm_carry_bytes())
     size_t bm_carry_size = 0;
@@ -342,14 +341,6 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         ctx->bm_guarded_copy = value ? 1 : 0;
         return EXABM4D_OK;
     }
-    if (std::strcmp(name, "stage_pairs") == 0) {
-        ctx->stage_pairs = value ? 1 : 0;
-        return EXABM4D_OK;
-    }
-    if (std::strcmp(name, "fuse_den_z") == 0) {
-        ctx->fuse_den_z = value ? 1 : 0;
-        return EXABM4D_OK;
-    }
     if (std::strcmp(name, "codec_version") == 0) {
         if (value != 1 && value != 2) return fail(ctx, EXABM4D_ERR_INVALID, "codec_version must be 1 or 2");
         ctx->codec_version = value;
@@ -360,7 +351,7 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "stage_pairvol") == 0) {      // Wiener gathers from an interleaved (noisy, basic) volume
-        g_stage_pairvol = value ? 1 : 0;
+        ctx->stage.pairvol = value ? 1 : 0;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "bm_carry") == 0) {           // block matching: carry between the tiles of a column (0 off, 1 automatic, 2 forced)
@@ -372,16 +363,12 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
         g_bm_xcd_mode = value < 0 ? 0 : (value > 16 ? 16 : value);   // >= 2: strips of that many tile rows
         return EXABM4D_OK;
     }
-    if (std::strcmp(name, "stage_quads") == 0) {        // Wiener stage: four (1) or two (0) waves per group
-        g_stage_quads = value ? 1 : 0;
-        return EXABM4D_OK;
-    }
     if (std::strcmp(name, "stage_strip") == 0) {        // tile-column order of the two-waves-per-group stage kernels (0 = raster, n = strips of n tile rows)
-        g_stage_strip = value > 0 ? value : 0;
+        ctx->stage.strip = value > 0 ? value : 0;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "stage_chunks") == 0) {       // diagnostic: z chunks of the stage kernels
-        g_stage_chunks = value > 0 ? value : 0;
+        ctx->stage.chunks = value > 0 ? value : 0;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "chunk_budget_mb") == 0) {
@@ -483,17 +470,33 @@ int exabm4d_blockmatch_plan(int nz, int ny, int nx, int batch, int32_t plan[6], 
     return EXABM4D_OK;
 }
 
+// Scratch layout of one pipeline run (run_pipeline below walks it in this order)
+namespace {
+struct PipeLayout {
+    size_t keys, num, basic, cw, tmp, pair, qscale, maxbits, total;
+};
+PipeLayout pipe_layout(size_t n, size_t nref, int batch, int stages) {
+    PipeLayout L;
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += align256(bytes); return o; };
+    L.keys = take(nref * MAXG * sizeof(uint32_t));
+    L.num = take(n * sizeof(long long));                        // numerator, int64 fixed point
+    L.basic = take(stages >= 2 ? n * sizeof(float) : 0);
+    L.cw = take(n * sizeof(unsigned long long));                // corner weights, int64 fixed point
+    L.tmp = take(n * sizeof(float));                            // x / y passes of the denominator convolution
+    L.pair = take(stages >= 2 ? 2 * n * sizeof(float) : 0);     // interleaved (noisy, basic) volume of the Wiener gathers
+    L.qscale = take((size_t)batch * 2 * sizeof(double));
+    L.maxbits = take((size_t)batch * sizeof(unsigned));
+    L.total = at;
+    return L;
+}
+}  // namespace
+
 size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages) {
     if (nz < 8 || ny < 8 || nx < 8 || batch < 1) return 0;
     const size_t n = (size_t)nz * ny * nx * (size_t)batch;
     const size_t nref = (size_t)grid_count(nz) * grid_count(ny) * grid_count(nx) * (size_t)batch;
-    // keys, num, den, [basic], and the two work volumes of the denominator convolution
-    size_t b = align256(nref * MAXG * sizeof(uint32_t)) + 2 * align256(n * sizeof(float));
-    if (stages >= 2) b += align256(n * sizeof(float));
-    // corner weights + ping-pong of the denominator convolution; with a Wiener stage also the
-    // interleaved (noisy, basic) volume its gathers read
-    b += align256((stages >= 2 ? 4 : 2) * n * sizeof(float));
-    return b;
+    return pipe_layout(n, nref, batch, stages).total;
 }
 
 // ---- staged entry points ---------------------------------------------------------------------------------
@@ -585,11 +588,13 @@ int exabm4d_match_decode(const uint32_t* keys16, int rz, int ry, int rx, int ny,
 
 int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
                       const uint32_t* keys, int nz, int ny, int nx, int batch, float sigma,
-                      const exabm4d_params* p, float* num, float* den) {
+                      const exabm4d_params* p, int data_exp, float* num, float* den) {
     if (!ctx || !noisy || !keys || !num || !den) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
     int rc = check_params(ctx, p);
     if (rc) return rc;
     if (!(sigma > 0.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "sigma must be > 0");
+    if (data_exp != EXABM4D_DATA_EXP_AUTO && (data_exp < -200 || data_exp > 200))
+        return fail(ctx, EXABM4D_ERR_INVALID, "data_exp must be EXABM4D_DATA_EXP_AUTO or within [-200, 200]");
     VolGeom g;
     rc = make_geom(ctx, nz, ny, nx, batch, g);
     if (rc) return rc;
@@ -599,12 +604,26 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
     const size_t n = (size_t)g.nvox * (size_t)batch;
-    rc = ensure_scratch(ctx, align256((basic ? 4 : 2) * n * sizeof(float)));
+    // int64 numerator, int64 corner weights, fp32 ping-pong, [pair volume], the units
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += align256(bytes); return o; };
+    const size_t o_num = take(n * sizeof(long long)), o_cw = take(n * sizeof(unsigned long long));
+    const size_t o_tmp = take(n * sizeof(float)), o_pair = take(basic ? 2 * n * sizeof(float) : 0);
+    const size_t o_qs = take((size_t)batch * 2 * sizeof(double)), o_mb = take((size_t)batch * sizeof(unsigned));
+    rc = ensure_scratch(ctx, at);
     if (rc) return rc;
-    HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, num,
-                              den, ctx->stream, ctx->stage_pairs, ctx->win1d,
-                              static_cast<float*>(ctx->scratch), 0,
-                              basic ? static_cast<float*>(ctx->scratch) + 2 * n : nullptr));
+    char* sc = static_cast<char*>(ctx->scratch);
+    long long* numq = reinterpret_cast<long long*>(sc + o_num);
+    unsigned long long* cw = reinterpret_cast<unsigned long long*>(sc + o_cw);
+    double* qs = reinterpret_cast<double*>(sc + o_qs);
+    HIP_TRY(ctx, hipMemsetAsync(sc + o_num, 0, o_tmp, ctx->stream));       // numerator and corner weights
+    HIP_TRY(ctx, launch_qscale(noisy, (size_t)g.nvox, batch, data_exp, reinterpret_cast<unsigned*>(sc + o_mb), qs,
+                               ctx->stream));
+    HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, qs, numq, cw,
+                              ctx->stream, ctx->stage, basic ? reinterpret_cast<float*>(sc + o_pair) : nullptr, 0));
+    HIP_TRY(ctx, launch_num_to_float(numq, qs, num, (size_t)g.nvox, batch, ctx->stream));
+    HIP_TRY(ctx, launch_den_from_corners(cw, reinterpret_cast<float*>(sc + o_tmp), den, g.nz, g.ny, g.nx, batch,
+                                         ctx->win1d, ctx->stream));
     return EXABM4D_OK;
 }
 
@@ -660,30 +679,27 @@ struct PhaseTimer {
 static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, uint16_t* out_u16,
                         const VolGeom& g, int batch, float sigma, const exabm4d_params* p,
                         int stages, float clip_lo, float clip_hi, float u16_offset, char* scratch,
-                        int noisy_guarded, const uint16_t* noisy16 = nullptr) {
+                        int noisy_guarded, int data_exp, const uint16_t* noisy16 = nullptr) {
     // noisy16: the same volume as uint16 counts XOR 0x8000, guarded like `noisy`, when the caller
     // is a uint16 pipeline: stage-1 matching then runs in integer arithmetic (bm_tile16_kernel),
     // provided its tables equal the float kernel's -- admission bound below 2^24, even row length
     // noisy_guarded: `noisy` lies inside the scratch allocation (mapped memory on both sides, see
     // ensure_scratch and bm_tile_kernel); a caller's own device buffer is not assumed to.
+    // data_exp: E of the numerator's unit: 17 from the uint16 entry points,
+    // EXABM4D_DATA_EXP_AUTO (from every volume's largest |v|) from the fp32 ones.
     const size_t n = (size_t)g.nvox * (size_t)batch;
-    uint32_t* keys = reinterpret_cast<uint32_t*>(scratch);
-    scratch += align256((size_t)g.nref * (size_t)batch * MAXG * sizeof(uint32_t));
-    float* num = reinterpret_cast<float*>(scratch);
-    scratch += align256(n * sizeof(float));
-    float* den = reinterpret_cast<float*>(scratch);
-    scratch += align256(n * sizeof(float));
-    float* basic = reinterpret_cast<float*>(scratch);  // only touched when stages >= 2
-    if (stages >= 2) scratch += align256(n * sizeof(float));
-    float* cwork = reinterpret_cast<float*>(scratch);  // 2 n floats: corner weights + ping-pong
+    const PipeLayout L = pipe_layout(n, (size_t)g.nref * (size_t)batch, batch, stages);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(scratch + L.keys);
+    long long* num = reinterpret_cast<long long*>(scratch + L.num);
+    float* basic = reinterpret_cast<float*>(scratch + L.basic);  // only touched when stages >= 2
+    unsigned long long* cw = reinterpret_cast<unsigned long long*>(scratch + L.cw);
+    float* tmp = reinterpret_cast<float*>(scratch + L.tmp);
+    float* pairvol = reinterpret_cast<float*>(scratch + L.pair);
+    double* qs = reinterpret_cast<double*>(scratch + L.qscale);
 
     const float thr = (float)((double)p->lambda_ht * (double)sigma);
     const float sigma2 = (float)((double)sigma * (double)sigma);
     hipStream_t s = ctx->stream;
-    // two-waves-per-group kernels: den = C (*) win; its z pass is fused into the normalisation kernels
-    // (cwork + n holds the x / y passes' result), unless the option asks for the separate pass
-    const bool fused = ctx->stage_pairs && ctx->fuse_den_z;
-    const int den_mode = fused ? 2 : ctx->stage_pairs;
     int pair_ready = 0;      // the first normalisation wrote the Wiener stage's (noisy, basic) volume
     if (ctx->profile)
         for (int i = 1; i < EXABM4D_PHASE_COUNT; i++) ctx->ev_used[i] = false;
@@ -693,10 +709,10 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
 
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_1);
-        HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
-        // the two-waves-per-group path writes den (convolution of the corner weights) instead of
-        // adding into it
-        if (!ctx->stage_pairs) HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+        HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(long long), s));
+        HIP_TRY(ctx, hipMemsetAsync(cw, 0, n * sizeof(unsigned long long), s));
+        HIP_TRY(ctx, launch_qscale(noisy, (size_t)g.nvox, batch, data_exp,
+                                   reinterpret_cast<unsigned*>(scratch + L.maxbits), qs, s));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);
@@ -710,23 +726,22 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
-        HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                  sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode));
+        HIP_TRY(ctx, launch_stage(noisy, nullptr, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, qs, num, cw,
+                                  s, ctx->stage));
+        HIP_TRY(ctx, launch_den_xy_from_corners(cw, tmp, g.nz, g.ny, g.nx, batch, ctx->win1d, s));
     }
     if (stages >= 2) {
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_BASIC);
-            if (fused)        // ... and, where it can, the Wiener stage's interleaved (noisy, basic) volume
-                HIP_TRY(ctx, launch_normalize_zconv(num, cwork + n, basic, nullptr, g.nz, g.ny, g.nx, batch,
-                                                    ctx->win1d, 1.0f, 0.0f, 0.0f, s,
-                                                    g_stage_pairvol ? noisy : nullptr, cwork + 2 * n, &pair_ready));
-            else
-                HIP_TRY(ctx, launch_normalize(num, den, basic, n, 1.0f, 0.0f, s));
+            // ... and, where it can, the Wiener stage's interleaved (noisy, basic) volume
+            HIP_TRY(ctx, launch_normalize_zconv(num, qs, tmp, basic, nullptr, g.nz, g.ny, g.nx, batch, ctx->win1d,
+                                                1.0f, 0.0f, 0.0f, s, ctx->stage.pairvol ? noisy : nullptr, pairvol,
+                                                &pair_ready));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_2);
-            HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(float), s));
-            if (!ctx->stage_pairs) HIP_TRY(ctx, hipMemsetAsync(den, 0, n * sizeof(float), s));
+            HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(long long), s));
+            HIP_TRY(ctx, hipMemsetAsync(cw, 0, n * sizeof(unsigned long long), s));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
@@ -735,20 +750,15 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
-            HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr,
-                                      sigma2, num, den, s, ctx->stage_pairs, ctx->win1d, cwork, den_mode,
-                                      cwork + 2 * n, pair_ready));
+            HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, qs, num, cw,
+                                      s, ctx->stage, pairvol, pair_ready));
+            HIP_TRY(ctx, launch_den_xy_from_corners(cw, tmp, g.nz, g.ny, g.nx, batch, ctx->win1d, s));
         }
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_NORMALIZE_OUT);
-        if (fused)
-            HIP_TRY(ctx, launch_normalize_zconv(num, cwork + n, out_f32, out_u16, g.nz, g.ny, g.nx, batch,
-                                                ctx->win1d, clip_lo, clip_hi, u16_offset, s));
-        else if (out_u16)
-            HIP_TRY(ctx, launch_normalize_u16(num, den, out_u16, n, u16_offset, s));
-        else
-            HIP_TRY(ctx, launch_normalize(num, den, out_f32, n, clip_lo, clip_hi, s));
+        HIP_TRY(ctx, launch_normalize_zconv(num, qs, tmp, out_f32, out_u16, g.nz, g.ny, g.nx, batch, ctx->win1d,
+                                            clip_lo, clip_hi, u16_offset, s));
     }
     return EXABM4D_OK;
 }
@@ -775,7 +785,7 @@ int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int n
     rc = ensure_scratch(ctx, exabm4d_scratch_bytes(nz, ny, nx, batch, stages));
     if (rc) return rc;
     return run_pipeline(ctx, in, out, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
-                        static_cast<char*>(ctx->scratch), 0);
+                        static_cast<char*>(ctx->scratch), 0, EXABM4D_DATA_EXP_AUTO);
 }
 
 int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
@@ -785,6 +795,8 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
     int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
     if (rc) return rc;
     const size_t n = (size_t)g.nvox * (size_t)batch;
+    if (!(std::fabs(offset) <= 65536.0f))     // |v - offset| < 2^17: the fixed unit of the uint16 pipelines
+        return fail(ctx, EXABM4D_ERR_INVALID, "offset must lie within [-65536, 65536]");
     const size_t base = exabm4d_scratch_bytes(nz, ny, nx, batch, stages);
     const size_t fbytes = align256(n * sizeof(float));
     rc = ensure_scratch(ctx, base + fbytes + GUARD_BYTES + align256(n * sizeof(uint16_t)));
@@ -798,7 +810,7 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
         HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream, noisy16));
     }
     return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
-                        scratch, 1, noisy16);
+                        scratch, 1, EXABM4D_DATA_EXP_U16, noisy16);
 }
 
 // Chunk-local mode: every chunk (core + halo, the halo cut off where the buffer ends) is denoised
@@ -815,6 +827,7 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
     if (nz < 1 || ny < 1 || nx < 1 || chunk < 1 || halo < 0 || halo > 64)
         return fail(ctx, EXABM4D_ERR_INVALID, "chunked: sizes >= 1, chunk >= 1, 0 <= halo <= 64");
     if (zc0 < 0 || zc1 > nz || zc0 >= zc1) return fail(ctx, EXABM4D_ERR_INVALID, "chunked: bad core plane range");
+    if (!(std::fabs(offset) <= 65536.0f)) return fail(ctx, EXABM4D_ERR_INVALID, "offset must lie within [-65536, 65536]");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     rc = ensure_window(ctx, (double)p->kaiser_beta);
     if (rc) return rc;
@@ -861,7 +874,7 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                     uint16_t* vol16 = reinterpret_cast<uint16_t*>(scratch + base + fbytes + GUARD_BYTES);
                     HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream, vol16));
                     rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f,
-                                      scratch, 1, offset_exact_in_fp32(offset) ? vol16 : nullptr);
+                                      scratch, 1, EXABM4D_DATA_EXP_U16, offset_exact_in_fp32(offset) ? vol16 : nullptr);
                     if (rc) return rc;
                     HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
                 }
@@ -1040,7 +1053,7 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     float* vol = reinterpret_cast<float*>(scratch + base);
     HIP_TRY(ctx, hipMemcpyAsync(vol, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
-                      scratch, 1);
+                      scratch, 1, EXABM4D_DATA_EXP_AUTO);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -63,31 +63,42 @@ size_t bm_carry_bytes(const VolGeom& g, int batch);   // device memory launch_bl
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
                              const uint16_t* vol16 = nullptr, void* carry_mem = nullptr);
-extern int g_stage_quads;    // Wiener stage: 1 = four waves per group (stage_quad_kernel), 0 = two (stage_half_kernel<true>)
-extern int g_stage_strip;    // stage kernels: tile columns walked in strips of n tile rows (0 = raster)
-extern int g_stage_chunks;   // diagnostic override of the stage kernels' z chunk count (0 = automatic)
+// Options of the stage kernels (per context since round 4; exabm4d_set_option "stage_pairvol" / "stage_strip" /
+// "stage_chunks"): Wiener gathers from an interleaved (noisy, basic) volume; tile columns walked in strips of n
+// tile rows (0 = raster); diagnostic override of the z chunk count (0 = automatic).
+struct StageOpts {
+    int pairvol = 1;
+    int strip = 3;
+    int chunks = 0;
+};
+// One stage: adds to num (int64 fixed point) and to the corner weights cw; see stage_kernels.hip.
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
-                        float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite,
-                        float* pair = nullptr, int pair_ready = 0);   // pair_ready: the caller has filled it     // pair: 2 n floats of scratch for the Wiener stage's
-                                                    // interleaved (noisy, basic) volume, or NULL
-extern int g_stage_pairvol;
-// den += C (*) win for the separable window win = k (x) k (x) k: fused x / y pass C -> tmp, z pass
-// den += conv(tmp) (den = conv(tmp) with `overwrite`: the caller need not zero den first).
-hipError_t launch_den_from_corners(float* C, float* tmp, float* den, int nz, int ny, int nx, int batch,
-                                   const float* win1d, int overwrite, hipStream_t s);
-// The pipelines' form (launch_stage with den_overwrite == 2): only the x / y passes run after the
-// stage kernel (C -> tmp = cwork + n) and the z pass rides with the normalisation:
-// out = num / (tmp (*)_z win), then clip (f32) or + offset, clamp, rint (uint16).
-hipError_t launch_den_xy_from_corners(float* C, float* tmp, int nz, int ny, int nx, int batch, const float* win1d,
-                                      hipStream_t s);
+                        float thr, float sigma2, const double* qscale, long long* num,
+                        unsigned long long* cw, hipStream_t stream, const StageOpts& opt,
+                        float* pair = nullptr, int pair_ready = 0);
+// The numerator's unit per volume: qscale[2 b] = 2^(43 - E), qscale[2 b + 1] = 2^(E - 43).
+// fixed_exp != INT32_MIN: E = fixed_exp for every volume (the uint16 entry points: 17); else E from the
+// largest |v| bit pattern of volume b of `vol` (maxbits: `batch` words of scratch).  No host synchronisation.
+hipError_t launch_qscale(const float* vol, size_t nvox, int batch, int fixed_exp, unsigned* maxbits,
+                         double* qscale, hipStream_t s);
+// den = fl32(cw 2^-40) (*) win for the separable window win = k (x) k (x) k: fused x / y pass cw -> tmp,
+// z pass tmp -> den (written).
+hipError_t launch_den_from_corners(const unsigned long long* cw, float* tmp, float* den, int nz, int ny, int nx,
+                                   int batch, const float* win1d, hipStream_t s);
+// The pipelines' form: only the x / y passes (cw -> tmp); the z pass rides with the normalisation:
+// out = fl32(fl64(num) 2^(E - 43)) / (tmp (*)_z win), then clip (f32) or + offset, clamp, rint (uint16).
+hipError_t launch_den_xy_from_corners(const unsigned long long* cw, float* tmp, int nz, int ny, int nx, int batch,
+                                      const float* win1d, hipStream_t s);
 // pair_src / pair_out (optional, fp32 output only): also write the interleaved (pair_src, out) volume of the
 // Wiener stage's gathers; *pair_written says whether this launch could do it (16-byte aligned float4 form)
-hipError_t launch_normalize_zconv(const float* num, const float* txy, float* out_f32, uint16_t* out_u16, int nz,
-                                  int ny, int nx, int batch, const float* win1d, float lo, float hi, float offset,
-                                  hipStream_t s, const float* pair_src = nullptr, float* pair_out = nullptr,
-                                  int* pair_written = nullptr);
+hipError_t launch_normalize_zconv(const long long* num, const double* qscale, const float* txy, float* out_f32,
+                                  uint16_t* out_u16, int nz, int ny, int nx, int batch, const float* win1d,
+                                  float lo, float hi, float offset, hipStream_t s, const float* pair_src = nullptr,
+                                  float* pair_out = nullptr, int* pair_written = nullptr);
+// staged entry point: num_f = fl32(fl64(num) 2^(E - 43))
+hipError_t launch_num_to_float(const long long* num, const double* qscale, float* out, size_t nvox, int batch,
+                               hipStream_t s);
 
 // ---- chunk-local mode (elementwise_kernels.hip) ------------------------------------------------------
 // One batch of equally shaped padded chunks out of a sub-grid of chunks (sgz x sgy x sgx chunks

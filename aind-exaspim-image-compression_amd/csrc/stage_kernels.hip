@@ -1,23 +1,23 @@
 // stage_kernels.hip -- grouped 4-D collaborative filtering + overlap-add aggregation
-// (SURVEY.md section 8 rows a-B2 .. a-B5).  Checker: oracle orc_stage.
+// (SURVEY.md section 8 rows a-B2 .. a-B5).  Checker: oracle orc_stage_q.
 //
 // Structure (MI355X-first; there is no reference kernel to follow):
-//   * A workgroup owns a 4x4 tile of reference-grid points in (y,x) and MARCHES along z.  The
-//     num/den accumulators of everything its groups can touch -- 18 z-planes x 30 x 30 voxels --
-//     live in an LDS ring (130 KB of the CU's 160 KB).  Blocks are added by plain LDS read-modify-writes under a workgroup lock;
-//     a plane leaves the ring exactly once, through global float atomics on whole 120-byte row
-//     segments.  Global atomic bytes drop from 64 KB to ~1.8 KB per group (the memory-side
-//     atomic units sustain ~1.3 TB/s, MI355X_MICROARCH.md "Global float atomics").
-//   * One wave processes one group.  The group's spectrum lives in registers: 8 x <16 x float>
-//     per lane (coefficient plane j, block k).  Each block goes through gather -> DCT(y) ->
-//     LDS transpose -> DCT(x) -> LDS transpose -> DCT(z); the Haar transform along the group
-//     and the shrinkage then run entirely in registers.
+//   * A workgroup owns a tile of reference-grid points in (y,x) and MARCHES along z.  The numerator
+//     sums of everything its groups can touch live in an LDS ring of 64-bit INTEGERS (fixed point,
+//     DESIGN.md 3.8); a plane leaves the ring exactly once, through 64-bit global integer atomics.
+//     Integer sums are associative, so the result does not depend on the order in which waves,
+//     workgroups or launches add: the GPU equals the oracle bit for bit and itself run for run.
+//   * Two waves process one group (half groups, below).  A half group's spectrum lives in registers;
+//     each block goes through gather -> DCT(y) -> LDS transpose -> DCT(x) -> LDS transpose -> DCT(z);
+//     the Haar transform along the group and the shrinkage then run in registers.
 //   * Lane layouts of one 8^3 block (8 values per lane):
 //       L1: lane = (z,x), regs = y    gather / scatter (LDS adds conflict-free: bank = 8z + x)
 //       L2: lane = (z,y), regs = x
 //       L3: lane = (x,y), regs = z    spectrum layout
-// All DCT arithmetic is the even/odd-folded 4-term fmaf chain of DESIGN.md 3.5 and is
-// bit-identical to the oracle; only the order of the atomic sums differs.
+// All DCT arithmetic is the even/odd-folded fmaf chain of DESIGN.md 3.5, bit-identical to the oracle.
+// (Rounds 1-3 also carried a one-wave-per-group kernel with an fp32 (num, den) ring under a lock and a
+// four-waves-per-group Wiener kernel; both measured slower -- DESIGN.md 5.2, 5.2i -- and were removed in
+// round 4 when the aggregation became integer.)
 #include <algorithm>
 #include <type_traits>
 
@@ -45,65 +45,14 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define STAMP_ADD(i, a, b)
 #endif
 
-constexpr int TILE_R = 4;                 // grid points per tile edge in y and x
-constexpr int REG = 30;                   // ring region edge: 12 (3 steps) + 8 (block) + 2*5
-constexpr int PS = 904;                   // ring plane stride: 900 padded to 8 (mod 32)
-constexpr int NPL = 18;                   // ring planes: z0-5 .. z0+12
 constexpr float HAAR_C = 0.70710678118654752440f;
-
-// Orthonormal Haar along the group axis on the first K elements of a <16 x float>.
-template <int K>
-__device__ __forceinline__ void haar_fwd(f16v& v) {
-#pragma unroll
-    for (int len = K; len > 1; len >>= 1) {
-        const int half = len >> 1;
-        float t[MAXG];
-#pragma unroll
-        for (int i = 0; i < half; i++) {
-            t[i] = (v[2 * i] + v[2 * i + 1]) * HAAR_C;
-            t[half + i] = (v[2 * i] - v[2 * i + 1]) * HAAR_C;
-        }
-#pragma unroll
-        for (int i = 0; i < len; i++) v[i] = t[i];
-    }
-}
-template <int K>
-__device__ __forceinline__ void haar_inv(f16v& v) {
-#pragma unroll
-    for (int len = 1; len < K; len <<= 1) {
-        float t[MAXG];
-#pragma unroll
-        for (int i = 0; i < len; i++) {
-            t[2 * i] = (v[i] + v[len + i]) * HAAR_C;
-            t[2 * i + 1] = (v[i] - v[len + i]) * HAAR_C;
-        }
-#pragma unroll
-        for (int i = 0; i < 2 * len; i++) v[i] = t[i];
-    }
-}
 
 #ifndef EXABM4D_GATHER_AUX
 #define EXABM4D_GATHER_AUX 0     // cache-policy bits of the gathers' buffer loads (A/B builds: 1 = sc0, 2 = nt, 3 = both)
 #endif
-// Issue the gather of one block (corner `src`) in layout L1 (hi = z, lo = x, regs y).
-__device__ __forceinline__ void gather8(const float* __restrict__ src, size_t sy, size_t sz, int hi,
-                                        int lo, float (&v)[8]) {
-    // uniform row base (SGPR pair) + one 32-bit lane offset: global_load with saddr, no 64-bit
-    // VALU address arithmetic per row (make_geom guarantees 7 planes fit 32-bit byte offsets)
-#ifdef EXABM4D_FAKE_GATHER
-    // timing probe only (wrong results): every instruction reads one contiguous 256-byte piece
-    const unsigned loff = (unsigned)(hi * 8 + lo);
-#else
-    const unsigned loff = (unsigned)hi * (unsigned)sz + (unsigned)lo;
-#endif
-#pragma unroll
-    for (int y = 0; y < 8; y++) v[y] = (src + (size_t)y * sy)[loff];
-}
-
-// The same with the lane's eight row offsets (hi * sz + y * sy + lo, constant for the whole
-// kernel) precomputed in registers: one uniform base per block (the corner) in an SGPR pair and no
-// scalar address arithmetic per row -- the unrolled half-group bodies otherwise hold 16 SGPRs of
-// row bases per block in flight and spill scalars into vector lanes.
+// Gather of one block in layout L1 (hi = z, lo = x, regs y), the lane's eight row offsets
+// (hi * sz + y * sy + lo, constant for the whole kernel) precomputed in registers: one uniform base
+// per block (the corner) in an SGPR pair and no scalar address arithmetic per row.
 // Buffer loads: the volume window of a group (planes rz - 5 ...) behind one 128-bit descriptor,
 // the block's corner as the scalar offset, the lane's row as the 32-bit vector offset -- no 64-bit
 // address arithmetic at all (hipcc does not form the global_load saddr + voffset variant here and
@@ -114,8 +63,6 @@ __device__ __forceinline__ void gather8v(__amdgpu_buffer_rsrc_t rsrc, int corner
     for (int y = 0; y < 8; y++)
         v[y] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff[y], corner, EXABM4D_GATHER_AUX));
 }
-
-typedef float f32v __attribute__((ext_vector_type(32)));
 
 // Packed Haar along the group axis: v[k] holds two independent sequences in .x / .y.
 template <int K>
@@ -162,464 +109,36 @@ __device__ __forceinline__ void gather8v2(__amdgpu_buffer_rsrc_t rsrc, int corne
     }
 }
 
-// Hard threshold.  Spectrum layout: S[jp][2k + c] = coefficient plane j = 2 jp + c of block k,
-// so that the Haar transforms of two coefficient planes run as one packed instruction stream.
-template <int K>
-__device__ __forceinline__ void shrink_ht(f32v (&S)[4], float thr, int& nnz) {
-#pragma unroll
-    for (int jp = 0; jp < 4; jp++) {
-        f2 x[MAXG];
-#pragma unroll
-        for (int k = 0; k < K; k++) x[k] = mk2(S[jp][2 * k], S[jp][2 * k + 1]);
-        haar_fwd2<K>(x);
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const bool k0 = fabsf(x[k].x) >= thr, k1 = fabsf(x[k].y) >= thr;
-            nnz += (k0 ? 1 : 0) + (k1 ? 1 : 0);
-            x[k] = mk2(k0 ? x[k].x : 0.0f, k1 ? x[k].y : 0.0f);
-        }
-        haar_inv2<K>(x);
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            S[jp][2 * k] = x[k].x;
-            S[jp][2 * k + 1] = x[k].y;
-        }
-    }
-}
-// Empirical Wiener.  W = e / (e + sigma^2) is evaluated as e * rcp(e + sigma^2) (v_rcp_f32:
-// within 2 ulp of the correctly rounded quotient the oracle uses; the stage result is compared
-// with an fp32 tolerance anyway because the aggregation order differs).  (An interleaved
-// <32 x float> layout like the hard-threshold one needs 8 x 32 contiguous registers and spills.)
-template <int K>
-__device__ __forceinline__ void shrink_wiener(f16v (&spec)[8], f16v (&bspec)[8], float sigma2,
-                                              float& sw) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        f2 x[MAXG];
-#pragma unroll
-        for (int k = 0; k < K; k++) x[k] = mk2(spec[j][k], bspec[j][k]);
-        haar_fwd2<K>(x);
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const float e = x[k].y * x[k].y;
-            const float W = e * __builtin_amdgcn_rcpf(e + sigma2);
-            sw += W * W;
-            x[k] = mk2(W * x[k].x, 0.0f);
-        }
-        f16v s;
-#pragma unroll
-        for (int k = 0; k < K; k++) s[k] = x[k].x;
-        haar_inv<K>(s);
-        spec[j] = s;
-    }
-}
-
-// The CU's LDS serves the instructions of all its waves in arrival order, so the ring accesses
-// of the lock holder are ordered against the next holder's by the lock word itself: only the
-// compiler has to be kept from moving ring accesses across lock / unlock (no s_waitcnt, which
-// would also drain the wave's outstanding global loads and atomics).
-__device__ __forceinline__ void ring_lock(int* lock, int lane) {
-    cbar();
-    if (lane == 0) {
-        int expected = 0;
-        while (!__hip_atomic_compare_exchange_strong(lock, &expected, 1, __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
-            expected = 0;
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    cbar();
-}
-__device__ __forceinline__ void ring_unlock(int* lock, int lane) {
-    cbar();
-    if (lane == 0)
-        __hip_atomic_store(lock, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    cbar();
-}
-// Workgroup barrier that waits for this wave's LDS operations only (a plain __syncthreads()
-// also waits for outstanding global atomics, whose completion nobody in the kernel needs).
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 struct TileGeom {
     int y0, x0;       // voxel coordinates of ring region element (0,0): first ref position - 5
     int nry, nrx;     // grid points of this tile in y and x (1..4)
 };
 
-// One wave, one group.
-template <bool WIENER>
-__device__ __forceinline__ bool process_group(const float* __restrict__ noisy,
-                                              const float* __restrict__ basic,
-                                              const uint32_t* __restrict__ kk, int rz, int ry,
-                                              int rx, const TileGeom& tg, size_t sy, size_t sz,
-                                              const DctTable& T, const float (&win)[8], float thr,
-                                              float sigma2, f2* ring, f2* tb, int* lock, int layer,
-                                              int target, int lane
-#ifdef EXABM4D_STAMPS
-                                              , unsigned long long (&st)[16]
-#endif
-                                              ) {
-    const int hi = lane >> 3, lo = lane & 7;
-    STAMP(t0);
-    const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
-    const int count = __popcll(__ballot(mykey != KEY_EMPTY));
-    int K = 1;
-    while (K * 2 <= count) K *= 2;
-
-    // Spectrum registers (layouts: see shrink_ht / shrink_wiener).
-    f32v S[4];                       // hard threshold: interleaved coefficient planes
-    f16v spec[WIENER ? 8 : 1];       // Wiener: noisy spectrum [plane][block]
-    f16v bspec[WIENER ? 8 : 1];      // Wiener: basic-estimate spectrum
-    if constexpr (WIENER) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            spec[j] = (f16v)(0.0f);
-            bspec[j] = (f16v)(0.0f);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) S[j] = (f32v)(0.0f);
-    }
-
-    // Forward transforms, two streams per iteration: (noisy k, basic k) for Wiener, blocks
-    // (k, k+1) for the hard-threshold stage.  The next iteration's gather is issued before the
-    // current pair is transformed so that its latency hides behind the arithmetic.
-    // Block corners are decoded once: lane k < 16 holds block k's displacement and its linear
-    // voxel offset; inside the loops a corner costs two v_readlane.
-    int my_dz, my_dy, my_dx;
-    code_to_disp(mykey & KEY_CMASK, my_dz, my_dy, my_dx);
-    const unsigned long long my_corner =
-        lane < MAXG ? (unsigned long long)(rz + my_dz) * sz + (unsigned long long)(ry + my_dy) * sy +
-                          (unsigned long long)(rx + my_dx)
-                    : 0ull;
-    const unsigned my_corner_lo = (unsigned)my_corner, my_corner_hi = (unsigned)(my_corner >> 32);
-    auto corner_of = [&](int k) -> size_t {
-        const unsigned lo32 = __builtin_amdgcn_readlane(my_corner_lo, k);
-        const unsigned hi32 = __builtin_amdgcn_readlane(my_corner_hi, k);
-        return ((size_t)hi32 << 32) | lo32;
-    };
-    const int kstep = WIENER ? 1 : 2;
-    float a[8], b[8], na[8] = {}, nb[8] = {};
-    f2 v2[8];
-    {
-        const size_t c0 = corner_of(0);
-        gather8(noisy + c0, sy, sz, hi, lo, a);
-        if (WIENER)
-            gather8(basic + c0, sy, sz, hi, lo, b);
-        else
-            gather8(noisy + corner_of(K > 1 ? 1 : 0), sy, sz, hi, lo, b);
-    }
-    for (int k = 0; k < K; k += kstep) {
-        const int kn = k + kstep;
-        if (kn < K) {
-            const size_t c0 = corner_of(kn);
-            gather8(noisy + c0, sy, sz, hi, lo, na);
-            if (WIENER)
-                gather8(basic + c0, sy, sz, hi, lo, nb);
-            else
-                gather8(noisy + corner_of(kn + 1), sy, sz, hi, lo, nb);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-        pair_fwd(T, tb, hi, lo, v2);
-        if constexpr (WIENER) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                spec[j][k] = v2[j].x;
-                bspec[j][k] = v2[j].y;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) S[j >> 1][2 * k + (j & 1)] = v2[j].x;
-            if (K > 1) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) S[j >> 1][2 * k + 2 + (j & 1)] = v2[j].y;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            a[j] = na[j];
-            b[j] = nb[j];
-        }
-    }
-
-    STAMP(t1);
-    STAMP_ADD(0, t0, t1);
-    float w;
-    if constexpr (!WIENER) {
-        int nnz = 0;
-        switch (K) {
-            case 16: shrink_ht<16>(S, thr, nnz); break;
-            case 8: shrink_ht<8>(S, thr, nnz); break;
-            case 4: shrink_ht<4>(S, thr, nnz); break;
-            case 2: shrink_ht<2>(S, thr, nnz); break;
-            default: shrink_ht<1>(S, thr, nnz); break;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
-        w = 1.0f / (sigma2 * (float)(nnz > 1 ? nnz : 1));
-    } else {
-        float sw = 0.0f;
-        switch (K) {
-            case 16: shrink_wiener<16>(spec, bspec, sigma2, sw); break;
-            case 8: shrink_wiener<8>(spec, bspec, sigma2, sw); break;
-            case 4: shrink_wiener<4>(spec, bspec, sigma2, sw); break;
-            case 2: shrink_wiener<2>(spec, bspec, sigma2, sw); break;
-            default: shrink_wiener<1>(spec, bspec, sigma2, sw); break;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
-        w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
-    }
-
-    float ww[8];
-#pragma unroll
-    for (int y = 0; y < 8; y++) ww[y] = w * win[y];
-    STAMP(t2);
-    STAMP_ADD(1, t1, t2);
-
-    // element (plane j, block k) of the filtered spectrum
-    auto sget = [&](int j, int k) -> float {
-        if constexpr (WIENER)
-            return spec[j][k];
-        else
-            return S[j >> 1][2 * k + (j & 1)];
-    };
-
-    // Ring offsets of the blocks, decoded once: lane k < 16 holds block k's first ring plane
-    // slot and its (y,x) offset inside the region.
-    const int my_slot0 = (rz + my_dz + 5 + NPL) % NPL;
-    const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
-    STAMP(t3);
-    STAMP_ADD(2, t2, t3);
-    // lock[0] = ring lock, lock[1] = groups aggregated so far, lock[2] = layers whose entry
-    // flush is complete.  This layer's retired planes must have left the ring first.
-    if (lane == 0) {
-        while (__hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= layer)
-            __builtin_amdgcn_s_sleep(4);
-    }
-
-    // Inverse 3-D DCT two blocks at a time and straight into the ring (layout L1: hi = z,
-    // lo = x, register index = y): the estimates never go back to the spectrum registers, and
-    // the lock is held only for the two read-modify-write bursts of a pair.
-    for (int k = 0; k < K; k += 2) {
-        const int k2 = (k + 1 < K) ? k + 1 : k;
-#pragma unroll
-        for (int j = 0; j < 8; j++) v2[j] = mk2(sget(j, k), sget(j, k2));
-        pair_inv(T, tb, hi, lo, v2);
-        int slot_a = __builtin_amdgcn_readlane(my_slot0, k) + hi;
-        slot_a -= slot_a >= NPL ? NPL : 0;
-        const int off_a = slot_a * PS + __builtin_amdgcn_readlane(my_yx, k) + lo;
-        int slot_b = __builtin_amdgcn_readlane(my_slot0, k2) + hi;
-        slot_b -= slot_b >= NPL ? NPL : 0;
-        const int off_b = slot_b * PS + __builtin_amdgcn_readlane(my_yx, k2) + lo;
-        STAMP(tl0);
-        ring_lock(lock, lane);
-        STAMP(tl1);
-        STAMP_ADD(3, tl0, tl1);
-        {
-            f2 acc[8];
-#pragma unroll
-            for (int y = 0; y < 8; y++) acc[y] = ring[off_a + y * REG];
-#pragma unroll
-            for (int y = 0; y < 8; y++)
-                ring[off_a + y * REG] = acc[y] + mk2(ww[y] * v2[y].x, ww[y]);
-        }
-        if (k2 != k) {
-            f2 acc[8];
-#pragma unroll
-            for (int y = 0; y < 8; y++) acc[y] = ring[off_b + y * REG];
-#pragma unroll
-            for (int y = 0; y < 8; y++)
-                ring[off_b + y * REG] = acc[y] + mk2(ww[y] * v2[y].y, ww[y]);
-        }
-        ring_unlock(lock, lane);
-        STAMP(tl2);
-        STAMP_ADD(4, tl1, tl2);
-    }
-    // The wave that aggregates the layer's last group closes the layer (it flushes the planes
-    // the next layer retires); everybody else runs ahead into the next layer's transforms.
-    int closer = 0;
-    if (lane == 0)
-        closer = (__hip_atomic_fetch_add(lock + 1, 1, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == target) ? 1 : 0;
-    return __builtin_amdgcn_readfirstlane(closer) != 0;
-}
-
-// Move ring planes [zlo, zhi) to global memory (float atomics: neighbouring tiles overlap) and
-// zero them.  Whole workgroup.  ROWS x REG voxels per plane, plane stride PSV.
-template <int ROWS = REG, int PSV = PS>
-__device__ __forceinline__ void flush_planes(f2* ring, float* __restrict__ num,
-                                             float* __restrict__ den, int zlo, int zhi,
-                                             const TileGeom& tg, const VolGeom& g, int nwaves) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int z = zlo + wave; z < zhi; z += nwaves) {          // one plane per wave
-        const int slot = (z + 5) % NPL;
-        f2* plane = ring + slot * PSV;
-        for (int rem = lane; rem < ROWS * REG; rem += 64) {
-            const f2 nd = plane[rem];
-            if (nd.y != 0.0f) {
-                const int ryy = rem / REG, rxx = rem - ryy * REG;
-                // den != 0 implies a block covered this voxel, so it lies inside the volume
-                const size_t go = ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx);
-                atomicAdd(num + go, nd.x);
-                atomicAdd(den + go, nd.y);
-                plane[rem] = mk2(0.0f, 0.0f);
-            }
-        }
-    }
-}
-
-// Same, by ONE wave (the wave that closes a layer).
-template <int ROWS = REG, int PSV = PS>
-__device__ __forceinline__ void flush_planes_wave(f2* ring, float* __restrict__ num,
-                                                  float* __restrict__ den, int zlo, int zhi,
-                                                  const TileGeom& tg, const VolGeom& g, int lane) {
-    for (int z = zlo; z < zhi; z++) {
-        const int slot = (z + 5) % NPL;
-        f2* plane = ring + slot * PSV;
-        for (int rem = lane; rem < ROWS * REG; rem += 64) {
-            const f2 nd = plane[rem];
-            if (nd.y != 0.0f) {
-                const int ryy = rem / REG, rxx = rem - ryy * REG;
-                const size_t go = ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx);
-                atomicAdd(num + go, nd.x);
-                atomicAdd(den + go, nd.y);
-                plane[rem] = mk2(0.0f, 0.0f);
-            }
-        }
-    }
-}
-
-template <bool WIENER, int NW>
-__global__ __launch_bounds__(NW * 64) void stage_tile_kernel(
-    const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
-    const uint32_t* __restrict__ keys_all, VolGeom g, DctTable T, const float* __restrict__ win_g,
-    float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ den_all, int tiles_x,
-    int layers_per_chunk) {
-    extern __shared__ __align__(16) float lds[];
-    f2* ring = reinterpret_cast<f2*>(lds);                 // [NPL][PS] (num, den) pairs
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    f2* tb = reinterpret_cast<f2*>(lds + 2 * NPL * PS + wave * 2 * TBUF);
-    int* lock = reinterpret_cast<int*>(lds + 2 * NPL * PS + NW * 2 * TBUF);
-
-    const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
-    const float* __restrict__ noisy = noisy_all + voff;
-    const float* __restrict__ basic = WIENER ? basic_all + voff : nullptr;
-    float* __restrict__ num = num_all + voff;
-    float* __restrict__ den = den_all + voff;
-    const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
-    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
-
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int iy0 = TILE_R * ty, ix0 = TILE_R * tx;
-    TileGeom tg;
-    tg.nry = min(TILE_R, g.gy - iy0);
-    tg.nrx = min(TILE_R, g.gx - ix0);
-    tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
-    tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
-    const int nrefs = tg.nry * tg.nrx;
-
-    const int izb = blockIdx.y * layers_per_chunk;
-    const int ize = min(g.gz, izb + layers_per_chunk);
-
-    for (int i = threadIdx.x; i < 2 * NPL * PS; i += NW * 64) lds[i] = 0.0f;
-    if (threadIdx.x == 0) {
-        lock[0] = 0;   // ring lock
-        lock[1] = 0;   // groups aggregated
-        lock[2] = 1;   // layer 0 needs no entry flush
-    }
-
-    // aggregation window of this lane in layout L1 (lane = (z,x), regs y)
-    float win[8];
-    {
-        const int hi = lane >> 3, lo = lane & 7;
-#pragma unroll
-        for (int y = 0; y < 8; y++) win[y] = win_g[(hi * 8 + y) * 8 + lo];
-    }
-    __syncthreads();
-
-#ifdef EXABM4D_STAMPS
-    unsigned long long st[16] = {};
-    const unsigned long long tk0 = stamp();
-#endif
-    // No workgroup barrier between layers: a wave only has to wait, right before it aggregates a
-    // group of layer L, until the planes that layer L retires have been flushed -- which the wave
-    // closing layer L-1 does.  Waves that finish a layer early start the next layer's transforms.
-    for (int iz = izb; iz < ize; iz++) {
-        const int layer = iz - izb;
-        const int z0 = grid_pos(iz, g.az, g.nz);
-        for (int r = wave; r < nrefs; r += NW) {
-            const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
-            const int iy = iy0 + jy, ix = ix0 + jx;
-            const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
-            const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
-            const bool closer = process_group<WIENER>(noisy, basic, kk, z0, ry, rx, tg, sy, sz, T,
-                                                      win, thr, sigma2, ring, tb, lock, layer,
-                                                      nrefs * (layer + 1), lane
-#ifdef EXABM4D_STAMPS
-                                                      , st
-#endif
-            );
-            if (closer) {
-                STAMP(tf0);
-                if (iz + 1 < ize) {
-                    const int zn = grid_pos(iz + 1, g.az, g.nz);
-                    flush_planes_wave(ring, num, den, z0 - RAD, zn - RAD, tg, g, lane);
-                }
-                cbar();
-                if (lane == 0)
-                    __hip_atomic_store(lock + 2, layer + 2, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                STAMP(tf1);
-                STAMP_ADD(5, tf0, tf1);
-            }
-        }
-    }
-    STAMP(tb0);
-    __syncthreads();
-    STAMP(tb1);
-    STAMP_ADD(6, tb0, tb1);
-    if (ize > izb) {
-        const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
-        flush_planes(ring, num, den, base, base + NPL, tg, g, NW);
-    }
-#ifdef EXABM4D_STAMPS
-    st[7] = stamp() - tk0;
-    if (lane == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[i + (WIENER ? 8 : 0)], st[i]);
-#endif
-}
-
-
 // =================================================================================================
-// Hard-threshold stage, two waves per group ("half groups").
+// Two waves per group ("half groups").
 //
 // One wave alone issues a VALU instruction every 4 cycles, two waves sharing a SIMD every 2
-// (MI355X_MICROARCH.md, per-instruction constants), and the whole-group-in-registers design above
-// cannot have two waves per SIMD: a group's spectrum alone is 128 registers.  Here a group is
-// split between the two waves of a pair: wave h (0/1) transforms blocks [h K/2, (h+1) K/2), so
-// its spectrum is 64 registers and eight waves (two per SIMD) fit.  The Haar transform along the
-// group splits exactly: its first log2(K)-1 levels act inside each half, and the last level
-// combines only the two halves' approximation coefficients -- 8 values per lane -- which the
-// waves swap through their transpose buffers.  Every operation is the one the single-wave path
-// (and the oracle) performs, in the same order, so results are bit-identical up to the order of
-// the aggregation sums.
+// (MI355X_MICROARCH.md, per-instruction constants), and a whole group's spectrum is 128 registers:
+// one wave per group cannot have two waves per SIMD.  A group is split between the two waves of a
+// pair: wave h (0/1) transforms blocks [h K/2, (h+1) K/2), so its spectrum is 64 registers and eight
+// waves (two per SIMD; twelve in the hard-threshold kernel) fit.  The Haar transform along the group
+// splits exactly: its first log2(K)-1 levels act inside each half, and the last level combines only
+// the two halves' approximation coefficients -- 8 values per lane -- which the waves swap through
+// their transpose buffers.  Every operation is the one the oracle performs, in the same order.
 //
 // The ring holds the numerator only.  The denominator of the aggregation is a convolution:
-// den(v) = sum over blocks of w_b * win(v - corner_b) = (C (*) win)(v) with C(c) = sum of the
+// den(v) = sum over blocks of u_b * win(v - corner_b) = (C (*) win)(v) with C(c) = sum of the
 // weights of the blocks whose corner is c, and win separable.  So a block costs ONE global atomic
-// (its weight onto its corner in C) instead of 512 ring updates for den, and the launcher turns C
-// into den with three 8-tap passes (launch_den_from_corners).
+// (its weight, as a 2^-40 fixed-point integer, onto its corner in C) instead of 512 ring updates, and
+// the launcher turns C into den with three 8-tap passes (launch_den_from_corners).
 //
-// The ring is fp64 and updated by LDS atomics, without any lock: gfx950 executes ds_add_f64
-// natively (measured 8 LDS cycles per wave-instruction, against 192 for ds_add_f32 and ~22 for a
-// plain read + write pair, tools/dbg/lds_atomic_bench.hip), the adds return nothing, so a wave
-// fires the 16 atomics of a block pair and moves on.  fp64 sums are also more accurate than the
-// fp32 read-modify-writes they replace.  18 planes of a 4x3 tile are 116 KB.
+// The ring is 64-bit INTEGER (fixed point, unit 2^(E - 43)) and updated by LDS atomics
+// without any lock: a term is fl64(est) * fl64(u * win) * 2^(43 - E) + 1.5 * 2^52 in ONE v_fma_f64 --
+// the exact product, rounded once, half to even -- whose low bits are the integer; ds_add_u64 returns
+// nothing, so a wave fires the 16 atomics of a block pair and moves on.  (Rounds 2-3 had an fp64 ring
+// under ds_add_f64: as fast, but its sums, the fp32 global atomics of the flush and the fp32 corner
+// weights depended on arrival order, and stage 2's match tables are discontinuous in the last bits of
+// the basic estimate: uint16 results moved by up to 4 counts between launches.)
 // =================================================================================================
 #ifndef EXABM4D_PRIO
 #define EXABM4D_PRIO 1                         // 0: no wave priorities (A/B builds)
@@ -693,8 +212,36 @@ struct HalfCfg : HalfGeom<EXABM4D_HT_NW, EXABM4D_HT_TY, EXABM4D_HT_TX, EXABM4D_H
 template <>
 struct HalfCfg<true> : HalfGeom<EXABM4D_WIE_NW, EXABM4D_WIE_TY, EXABM4D_WIE_TX, EXABM4D_WIE_NPL> {};
 constexpr int HNCNT = 8;                      // per-layer report counters
-typedef double ring_t;                        // LDS fp64 atomic add is native on gfx950 (8 cycles per
-                                              // wave-instruction; ds_add_f32 takes 192): lock-free ring
+typedef long long ring_t;                     // 64-bit fixed point: ds_add_u64, lock-free ring
+constexpr double RINT_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: fl64(x + MAGIC) holds rint(x) in its low bits
+__device__ __forceinline__ long long magic_bits(double m) {
+    // bits(1.5 * 2^52) = 0x43380000'00000000: only the high word is touched (one v_sub_u32)
+    const unsigned long long b = (unsigned long long)__double_as_longlong(m);
+    const unsigned hi = (unsigned)(b >> 32) - 0x43380000u;
+    return (long long)(((unsigned long long)hi << 32) | (b & 0xFFFFFFFFull));
+}
+// R(d) of DESIGN.md 3.7 for two values at once: integer-subtraction seed, three Newton steps as fused
+// multiply-adds (v_pk_fma_f32) -- IEEE operations only, so the oracle produces the same bits (v_rcp_f32
+// is a table the CPU does not have), and about what two quarter-rate v_rcp_f32 cost.
+__device__ __forceinline__ f2 rcp_nr2(f2 d) {
+    f2 r = mk2(__uint_as_float(0x7EF311C7u - __float_as_uint(d.x)), __uint_as_float(0x7EF311C7u - __float_as_uint(d.y)));
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const f2 t = __builtin_elementwise_fma(-d, r, (f2)(1.0f));
+        r = __builtin_elementwise_fma(t, r, r);
+    }
+    return r;
+}
+// W = e * R(e + sigma^2) and this lane's share of sum W^2: bits(fl(1 + W^2)) accumulated as integers --
+// each is 0x3F800000 + W^2 in units of 2^-23; the caller takes the 0x3F800000s off again (WSQ_BIAS per call)
+__device__ __forceinline__ f2 wiener_w2(f2 e, float sigma2, unsigned& acc) {
+    const f2 W = e * rcp_nr2(e + sigma2);
+    const f2 q = __builtin_elementwise_fma(W, W, (f2)(1.0f));
+    acc += __float_as_uint(q.x);
+    acc += __float_as_uint(q.y);
+    return W;
+}
+constexpr unsigned WSQ_BIAS = 2u * 0x3F800000u;
 
 // Wait until *flag >= want (lane 0 spins; LDS serves the CU's instructions in arrival order, so
 // data the partner wrote before raising the flag is visible once the flag is).
@@ -763,10 +310,10 @@ __device__ __forceinline__ void half_unshrink_local(f16v (&S)[4], const f2 (&app
     }
 }
 
-// Numerator ring of the two-waves-per-group kernels: move plane z to global memory (float atomics:
-// neighbouring tiles overlap) and zero it.  One wave.
+// Numerator ring: move plane z to global memory (64-bit integer atomics: neighbouring tiles and z chunks
+// overlap; the sums are exact, so their order is immaterial) and zero it.  One wave.
 template <class C>
-__device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict__ num, int z,
+__device__ __forceinline__ void flush_num_plane(ring_t* ring, long long* __restrict__ num, int z,
                                                 const TileGeom& tg, const VolGeom& g, int lane) {
     constexpr int REG = C::COLS;
     ring_t* plane = ring + ((z + 5) % C::NPL) * C::PS;
@@ -777,15 +324,18 @@ __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict_
     for (int rem0 = lane; rem0 < N; rem0 += 64 * U) {
         ring_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = (rem0 + 64 * u < N) ? plane[rem0 + 64 * u] : 0.0;
+        for (int u = 0; u < U; u++) v[u] = (rem0 + 64 * u < N) ? plane[rem0 + 64 * u] : 0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int rem = rem0 + 64 * u;
-            if (v[u] != 0.0) {
+            if (v[u] != 0) {
                 const int ryy = rem / REG, rxx = rem - ryy * REG;
                 // a non-zero sum implies a block covered this voxel, so it lies inside the volume
-                atomicAdd(num + ((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx), (float)v[u]);
-                plane[rem] = 0.0;
+                // (64-bit integer atomic, no return value: global_atomic_add_x2)
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(num) +
+                                           (((size_t)z * g.ny + (tg.y0 + ryy)) * g.nx + (tg.x0 + rxx)),
+                                       (unsigned long long)v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                plane[rem] = 0;
             }
         }
     }
@@ -803,7 +353,7 @@ __device__ __forceinline__ void flush_num_plane(ring_t* ring, float* __restrict_
 #define EXABM4D_HELP_FLUSH 1
 #endif
 template <class C>
-__device__ __forceinline__ bool flush_take(int* lock, ring_t* ring, float* __restrict__ num, const TileGeom& tg,
+__device__ __forceinline__ bool flush_take(int* lock, ring_t* ring, long long* __restrict__ num, const TileGeom& tg,
                                            const VolGeom& g, int izb, int lane) {
     int w = lane == 0 ? __hip_atomic_load(lock + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
     w = __builtin_amdgcn_readfirstlane(w);
@@ -840,11 +390,11 @@ __device__ __forceinline__ bool flush_take(int* lock, ring_t* ring, float* __res
 // interleaved noisy and basic in one 128-register array that stayed live to the end and spilled
 // 54 registers per lane: 280 GB of scratch traffic per 1024^3 launch.)
 // Local part: Haar over the half of both spectra, Wiener-filter the detail coefficients
-// (W = e / (e + sigma^2) from the basic estimate, evaluated as e * rcp: see shrink_wiener), hand
-// back the approximation pairs.  The filtered details stay in S.
+// (W = e R(e + sigma^2) from the basic estimate), hand back the approximation pairs.  The
+// filtered details stay in S; `sw` collects the lane's share of sum W^2 as biased integers (wiener_w2).
 template <int KH>
 __device__ __forceinline__ void wiener_half_local(f16v (&S)[4], const f16v (&SB)[4], float sigma2,
-                                                  float& sw, f2 (&approx)[8]) {
+                                                  unsigned& sw, f2 (&approx)[8]) {
 #pragma unroll
     for (int jp = 0; jp < 4; jp++) {
         f16v A = S[jp];
@@ -861,14 +411,13 @@ __device__ __forceinline__ void wiener_half_local(f16v (&S)[4], const f16v (&SB)
         approx[4 + jp] = y[0];
 #pragma unroll
         for (int k = 1; k < KH; k++) {
-            const f2 e = y[k] * y[k];
-            const f2 t = e + sigma2;
-            const f2 W = e * mk2(__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y));
-            sw += W.x * W.x;
-            sw += W.y * W.y;
+            const f2 W = wiener_w2(y[k] * y[k], sigma2, sw);
             const f2 f = W * x[k];
             A[2 * k] = f.x;
             A[2 * k + 1] = f.y;
+            // one coefficient pair at a time: interleaving the Newton chains of several k for latency
+            // costs the registers the two spectra leave (30 spilled without this)
+            __builtin_amdgcn_sched_barrier(0);
         }
         S[jp] = A;
     }
@@ -881,10 +430,10 @@ template <bool WIENER, typename TableT>
 __device__ __forceinline__ bool process_half_group(
     const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
     int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
-    const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, ring_t* ring,
-    float* __restrict__ cvol, f2* tb,
+    const float (&win)[8], const float* __restrict__ win_g, float thr, float sigma2, double up, ring_t* ring,
+    unsigned long long* __restrict__ cvol, f2* tb,
     f2* partner_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int& seen, int layer, int target,
-    int lane, long long g_nvox, float* __restrict__ num, const VolGeom& g, int izb,
+    int lane, long long g_nvox, long long* __restrict__ num, const VolGeom& g, int izb,
     const f2* __restrict__ pair
 #ifdef EXABM4D_STAMPS
     , unsigned long long (&st)[16]
@@ -1071,7 +620,7 @@ __device__ __forceinline__ bool process_half_group(
         // `tally` is this lane's share of the aggregation-weight statistic: the count of kept
         // coefficients (hard threshold, as int bits) or the sum of squared Wiener weights.
         int nnz = 0;
-        float sw = 0.0f;
+        unsigned sw = 0;               // Wiener: sum of bits(fl(1 + W^2)), see wiener_w2
         f2 approx[NP];                 // Wiener: [0, 4) noisy plane pairs, [4, 8) basic plane pairs
         if constexpr (WIENER)
             wiener_half_local<KH>(S, SB, sigma2, sw, approx);
@@ -1084,7 +633,7 @@ __device__ __forceinline__ bool process_half_group(
             // previous exchange before my last inverse transforms started)
 #pragma unroll
             for (int jp = 0; jp < NP; jp++) tb[jp * 64 + lane] = approx[jp];
-            tb[NP * 64 + lane] = mk2(WIENER ? sw : __int_as_float(nnz), 0.0f);
+            tb[NP * 64 + lane] = mk2(__int_as_float(WIENER ? (int)sw : nnz), 0.0f);
             raise_flag(sync + wave, seq, lane);
             STAMP(te0);
             wait_flag(sync + partner, seq, lane);
@@ -1097,7 +646,7 @@ __device__ __forceinline__ bool process_half_group(
             cbar();
             raise_flag(sync + HNW + wave, seq, lane);          // partner may reuse its buffer
             if constexpr (WIENER)
-                sw += theirs;
+                sw += __float_as_uint(theirs);
             else
                 nnz += __float_as_int(theirs);
 #pragma unroll
@@ -1108,14 +657,8 @@ __device__ __forceinline__ bool process_half_group(
                     const f2 b0 = half ? other[4 + jp] : approx[4 + jp];
                     const f2 b1 = half ? approx[4 + jp] : other[4 + jp];
                     const f2 u0 = (b0 + b1) * HAAR_C, u1 = (b0 - b1) * HAAR_C;
-                    const f2 e0 = u0 * u0, e1 = u1 * u1;
-                    const f2 d0 = e0 + sigma2, d1 = e1 + sigma2;
-                    const f2 W0 = e0 * mk2(__builtin_amdgcn_rcpf(d0.x), __builtin_amdgcn_rcpf(d0.y));
-                    const f2 W1 = e1 * mk2(__builtin_amdgcn_rcpf(d1.x), __builtin_amdgcn_rcpf(d1.y));
-                    sw += W0.x * W0.x;
-                    sw += W0.y * W0.y;
-                    sw += W1.x * W1.x;
-                    sw += W1.y * W1.y;
+                    const f2 W0 = wiener_w2(u0 * u0, sigma2, sw);
+                    const f2 W1 = wiener_w2(u1 * u1, sigma2, sw);
                     t0 = W0 * t0;
                     t1 = W1 * t1;
                 } else {
@@ -1126,16 +669,13 @@ __device__ __forceinline__ bool process_half_group(
                     t1 = mk2(q0 ? t1.x : 0.0f, q1 ? t1.y : 0.0f);
                 }
                 top[jp] = half ? (t0 - t1) * HAAR_C : (t0 + t1) * HAAR_C;
+                if constexpr (WIENER) __builtin_amdgcn_sched_barrier(0);      // as in wiener_half_local
             }
         } else {
 #pragma unroll
             for (int jp = 0; jp < 4; jp++) {
                 if constexpr (WIENER) {
-                    const f2 e = approx[4 + jp] * approx[4 + jp];
-                    const f2 d = e + sigma2;
-                    const f2 W = e * mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
-                    sw += W.x * W.x;
-                    sw += W.y * W.y;
+                    const f2 W = wiener_w2(approx[4 + jp] * approx[4 + jp], sigma2, sw);
                     top[jp] = W * approx[jp];
                 } else {
                     const bool p0 = fabsf(approx[jp].x) >= thr, p1 = fabsf(approx[jp].y) >= thr;
@@ -1145,28 +685,43 @@ __device__ __forceinline__ bool process_half_group(
             }
         }
         half_unshrink_local<KH>(S, top);
+        // group weight u = 1 / max(statistic, 1) (IEEE division).  Both statistics are
+        // integers, so neither the split into halves nor the order of the lane reduction matters.
         float w;
         if constexpr (WIENER) {
+            // wiener_w2 calls behind `sw`: 4 (KH - 1) per half + 8 at the top level (4 for a one-block group)
+            sw -= (K > 1 ? 8u * (unsigned)(KH - 1) + 8u : 4u) * WSQ_BIAS;
+            // a lane's share is < 2^31 (128 coefficients of at most 2^23 + 1), the group's < 2^37
+            unsigned lo16 = sw & 0xFFFFu, hi16 = sw >> 16;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
-            w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
+            for (int off = 32; off >= 1; off >>= 1) {
+                lo16 += __shfl_xor(lo16, off);
+                hi16 += __shfl_xor(hi16, off);
+            }
+            const double q = (double)hi16 * 65536.0 + (double)lo16;           // exact
+            const float stat = (float)(q * (1.0 / 8388608.0));
+            w = 1.0f / (stat > 1.0f ? stat : 1.0f);
         } else {
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) nnz += __shfl_xor(nnz, off);
-            w = 1.0f / (sigma2 * (float)(nnz > 1 ? nnz : 1));
+            w = 1.0f / (float)(nnz > 1 ? nnz : 1);
         }
-        float ww[8];
+        // fl64(fl32(u * win)) * 2^(43 - E): the second factor of a term's single fused multiply-add
+        double ww[8];
         if constexpr (WIENER) {
             // the Wiener kernel has no registers to spare for the window between groups: its 8
             // values per lane are re-read here (2 KB table, L1-resident)
 #pragma unroll
-            for (int y = 0; y < 8; y++) ww[y] = w * win_g[(hi * 8 + y) * 8 + lo];
+            for (int y = 0; y < 8; y++) ww[y] = (double)(w * win_g[(hi * 8 + y) * 8 + lo]) * up;
         } else {
 #pragma unroll
-            for (int y = 0; y < 8; y++) ww[y] = w * win[y];
+            for (int y = 0; y < 8; y++) ww[y] = (double)(w * win[y]) * up;
         }
-        // denominator: this half's blocks put their weight onto their corners (see above)
-        if (lane >= kb && lane < kb + KH) atomicAdd(cvol + (size_t)my_corner, w);
+        // denominator: this half's blocks put their weight, rint(u 2^40), onto their corners (see above)
+        if (lane >= kb && lane < kb + KH)
+            __hip_atomic_fetch_add(cvol + (size_t)my_corner,
+                                   (unsigned long long)magic_bits(__builtin_fma((double)w, 1099511627776.0, RINT_MAGIC)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         const int my_slot0 = (rz + my_dz + 5 + HNPL) % HNPL;
         const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
@@ -1221,10 +776,12 @@ __device__ __forceinline__ bool process_half_group(
             return slot * HPS + __builtin_amdgcn_readlane(my_yx, k) + lo;
         };
         auto ring_add = [&](int off, const f2 (&v)[8], int comp) {
-            // lock-free: fp64 LDS atomics, no return value
+            // lock-free: 64-bit integer LDS atomics, no return value.  term = rint(est * ww), the exact
+            // product rounded once (v_cvt_f64_f32, v_fma_f64, v_sub_u32, ds_add_u64 per voxel)
 #pragma unroll
             for (int y = 0; y < 8; y++)
-                __hip_atomic_fetch_add(ring + off + y * REG, (double)(ww[y] * (comp ? v[y].y : v[y].x)),
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(ring + off + y * REG),
+                                       (unsigned long long)magic_bits(__builtin_fma((double)(comp ? v[y].y : v[y].x), ww[y], RINT_MAGIC)),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         if constexpr (KH >= 4 && EXABM4D_X2INV) {
@@ -1302,12 +859,13 @@ template <bool WIENER>
 __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
     const uint32_t* __restrict__ keys_all, VolGeom g, HalfTable T, const float* __restrict__ win_g,
-    float thr, float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x,
-    int layers_per_chunk, const f2* __restrict__ pair_all, int strip) {
+    float thr, float sigma2, const double* __restrict__ qscale, long long* __restrict__ num_all,
+    unsigned long long* __restrict__ cvol_all, int tiles_x, int layers_per_chunk, const f2* __restrict__ pair_all,
+    int strip) {
     using C = HalfCfg<WIENER>;
     constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, HTY = C::TY, HTX = C::TX;
     extern __shared__ __align__(16) float lds[];
-    ring_t* ring = reinterpret_cast<ring_t*>(lds);         // [HNPL][HPS] numerator sums (fp64)
+    ring_t* ring = reinterpret_cast<ring_t*>(lds);         // [HNPL][HPS] numerator sums (int64 fixed point)
     // readfirstlane: the wave index steers register indexing below and must be provably uniform
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * C::TBW);
@@ -1321,8 +879,9 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const float* __restrict__ noisy = noisy_all + voff;
     const float* __restrict__ basic = WIENER ? basic_all + voff : nullptr;
     const f2* __restrict__ pair = (WIENER && pair_all) ? pair_all + voff : nullptr;
-    float* __restrict__ num = num_all + voff;
-    float* __restrict__ cvol = cvol_all + voff;
+    long long* __restrict__ num = num_all + voff;
+    unsigned long long* __restrict__ cvol = cvol_all + voff;
+    const double up = qscale[2 * blockIdx.z];              // 2^(43 - E) of this volume
     const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
     const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
 
@@ -1349,7 +908,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     const int izb = blockIdx.y * layers_per_chunk;
     const int ize = min(g.gz, izb + layers_per_chunk);
 
-    for (int i = threadIdx.x; i < 2 * HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;
+    for (int i = threadIdx.x; i < 2 * HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;      // (all-zero bits: the int64 ring)
     // lock[1] = layers retired (in order); the ring itself needs no lock (fp64 LDS atomics)
     if (threadIdx.x < 4 + 2 * HNW + HNCNT) lock[threadIdx.x] = 0;
 
@@ -1399,7 +958,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
             }
 #endif
             const bool closer = process_half_group<WIENER>(
-                noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, ring, cvol, tb,
+                noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win, win_g, thr, sigma2, up, ring, cvol, tb,
                 partner_tb, lock, sync, cnt, wave, seq, seen, layer, 2 * nrefs, lane, g.nvox, num, g, izb, pair
 #ifdef EXABM4D_STAMPS
                 , st
@@ -1457,463 +1016,6 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
 #endif
 }
 
-// =================================================================================================
-// Wiener stage, FOUR waves per group ("quarter groups"; round 3).
-//
-// The two-waves-per-group Wiener kernel above holds two half spectra (noisy and basic estimate: 128
-// spectrum registers, 245 in all) and is held at two waves per SIMD; the hard-threshold kernel gained
-// 11 % from its third wave.  The Haar transform along the group splits one level further: a member m
-// of a team of four transforms blocks [m K/4, (m+1) K/4), runs the log2(K/4) local levels and the
-// Wiener filter of its detail coefficients, and the last TWO levels act on the four members'
-// approximation coefficients only.  Those (8 float2 per lane and member: four coefficient-plane
-// pairs of the noisy and of the basic spectrum) go through the transpose buffers, every member
-// evaluates the two top levels redundantly -- the same operations in the same order as the oracle's
-// recursion, so spectra stay bit-identical -- and keeps its own quarter.  Two spectra of at most 4
-// blocks are 64 registers: twelve waves (three teams) per workgroup, three per SIMD.
-// Groups of 8 / 4 blocks give every member 2 / 1; a group of 2 occupies two members, a group of 1
-// one; the others idle through it (and still report to the layer counter).
-// =================================================================================================
-// MEASURED (round 3, one box, A/B/A/B at 1024^3): 293 ms against 228 ms for the two-waves-per-group
-// kernel -- the third wave per SIMD does not pay for the second exchange round, the redundant top
-// levels, 23 spilled registers at the 168-register cap and the 8-groups-on-3-teams imbalance.  Kept as
-// an option (exabm4d_set_option("stage_quads", 1), parity-tested), OFF by default.  DESIGN.md 5.2i.
-#ifndef EXABM4D_WIE_QUADS
-#define EXABM4D_WIE_QUADS 0                    // 1: the Wiener stage runs on teams of four waves by default
-#endif
-#ifndef EXABM4D_QUAD_NW
-#define EXABM4D_QUAD_NW 12
-#endif
-#ifndef EXABM4D_QUAD_TY
-#define EXABM4D_QUAD_TY 2
-#endif
-#ifndef EXABM4D_QUAD_TX
-#define EXABM4D_QUAD_TX 4
-#endif
-#ifndef EXABM4D_QUAD_NPL
-#define EXABM4D_QUAD_NPL 18
-#endif
-struct QuadCfg : HalfGeom<EXABM4D_QUAD_NW, EXABM4D_QUAD_TY, EXABM4D_QUAD_TX, EXABM4D_QUAD_NPL> {
-    static_assert(EXABM4D_QUAD_NW % 4 == 0, "teams of four waves");
-};
-typedef float f8v __attribute__((ext_vector_type(8)));
-
-// Local levels of a member with KQ blocks: Haar over its blocks of both spectra, Wiener-filter its
-// detail coefficients, hand back the approximation pairs (noisy [0, 4), basic [4, 8)).
-template <int KQ>
-__device__ __forceinline__ void wiener_quarter_local(f8v (&S)[4], const f8v (&SB)[4], float sigma2, float& sw,
-                                                     f2 (&approx)[8]) {
-#pragma unroll
-    for (int jp = 0; jp < 4; jp++) {
-        f8v A = S[jp];
-        const f8v B = SB[jp];
-        f2 x[MAXG], y[MAXG];
-#pragma unroll
-        for (int k = 0; k < KQ; k++) {
-            x[k] = mk2(A[2 * k], A[2 * k + 1]);
-            y[k] = mk2(B[2 * k], B[2 * k + 1]);
-        }
-        haar_fwd2<KQ>(x);
-        haar_fwd2<KQ>(y);
-        approx[jp] = x[0];
-        approx[4 + jp] = y[0];
-#pragma unroll
-        for (int k = 1; k < KQ; k++) {
-            const f2 e = y[k] * y[k];
-            const f2 t = e + sigma2;
-            const f2 W = e * mk2(__builtin_amdgcn_rcpf(t.x), __builtin_amdgcn_rcpf(t.y));
-            sw += W.x * W.x;
-            sw += W.y * W.y;
-            const f2 f = W * x[k];
-            A[2 * k] = f.x;
-            A[2 * k + 1] = f.y;
-        }
-        S[jp] = A;
-    }
-}
-template <int KQ>
-__device__ __forceinline__ void quarter_unshrink_local(f8v (&S)[4], const f2 (&approx)[4]) {
-#pragma unroll
-    for (int jp = 0; jp < 4; jp++) {
-        f8v A = S[jp];
-        f2 x[MAXG];
-        x[0] = approx[jp];
-#pragma unroll
-        for (int k = 1; k < KQ; k++) x[k] = mk2(A[2 * k], A[2 * k + 1]);
-        haar_inv2<KQ>(x);
-#pragma unroll
-        for (int k = 0; k < KQ; k++) {
-            A[2 * k] = x[k].x;
-            A[2 * k + 1] = x[k].y;
-        }
-        S[jp] = A;
-    }
-}
-// W = e / (e + sigma^2) of a packed pair, evaluated as e * rcp (see shrink_wiener); adds W^2 to sw
-__device__ __forceinline__ f2 wiener_w(f2 u, float sigma2, float& sw) {
-    const f2 e = u * u;
-    const f2 d = e + sigma2;
-    const f2 W = e * mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
-    sw += W.x * W.x;
-    sw += W.y * W.y;
-    return W;
-}
-
-// One wave, one quarter of a group.  `sync` = int[2 * NW]: ready[w], ack[w]; `seq` = exchanges this
-// team has done so far (all four waves count alike, also the ones that idle through a small group).
-// Returns true for the wave that completes the layer.
-template <typename TableT>
-__device__ __forceinline__ bool process_quad_group(
-    const float* __restrict__ noisy, const float* __restrict__ basic, const uint32_t* __restrict__ kk,
-    int rz, int ry, int rx, const TileGeom& tg, size_t sy, size_t sz, const TableT& T,
-    const float* __restrict__ win_g, float sigma2, ring_t* ring, float* __restrict__ cvol, f2* tb,
-    f2* team_tb, int* lock, int* sync, int* cnt, int wave, int& seq, int& seen, int layer, int target,
-    int lane, long long g_nvox) {
-    using C = QuadCfg;
-    constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, REG = C::COLS;
-    constexpr int NP = 8;                      // f2 values per lane a member publishes
-    const int hi = lane >> 3, lo = lane & 7;
-    const int member = wave & 3, team0 = wave & ~3;
-    const uint32_t mykey = lane < MAXG ? kk[lane] : KEY_EMPTY;
-    const int count = __popcll(__ballot(mykey != KEY_EMPTY));
-    int K = 1;
-    while (K * 2 <= count) K *= 2;
-    const int A = K < 4 ? K : 4;               // members that hold blocks
-    const int KQ = K > 4 ? K / 4 : 1;          // blocks per member
-    const int kb = member * KQ;                // first block of this member
-    const bool active = member < A;
-    if (K > 1) seq++;
-
-    auto body = [&](auto KQc) {
-        constexpr int KQ = decltype(KQc)::value;
-        f8v S[4], SB[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            S[j] = (f8v)(0.0f);
-            SB[j] = (f8v)(0.0f);
-        }
-        int my_dz, my_dy, my_dx;
-        code_to_disp(mykey & KEY_CMASK, my_dz, my_dy, my_dx);
-        const unsigned long long my_corner =
-            lane < MAXG ? (unsigned long long)(rz + my_dz) * sz +
-                              (unsigned long long)(ry + my_dy) * sy + (unsigned long long)(rx + my_dx)
-                        : 0ull;
-        const int zb = max(rz - RAD, 0);
-        const size_t win_off = (size_t)zb * sz;
-        const size_t win_left = (size_t)g_nvox - win_off;
-        const int win_bytes = (int)min(win_left * sizeof(float), (size_t)0x7FFFFFFFu * 2u);
-        const __amdgpu_buffer_rsrc_t noisy_r = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(noisy + win_off), 0, win_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t basic_r = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(basic + win_off), 0, win_bytes, 0x00020000);
-        const int my_rel = lane < MAXG ? (int)(4u * (unsigned)(my_corner - win_off)) : 0;
-        auto corner_of = [&](int k) -> int { return __builtin_amdgcn_readlane(my_rel, k); };
-        float a[8], b[8];
-        f2 v2[8];
-        unsigned voff[8];
-#pragma unroll
-        for (int y = 0; y < 8; y++)
-            voff[y] = 4u * ((unsigned)hi * (unsigned)sz + (unsigned)y * (unsigned)sy + (unsigned)lo);
-        if constexpr (KQ == 1) {
-            const size_t c0 = corner_of(kb);
-            gather8v(noisy_r, c0, voff, a);
-            gather8v(basic_r, c0, voff, b);
-#pragma unroll
-            for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-            pair_fwd<false>(T, tb, hi, lo, v2);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                S[j >> 1][j & 1] = v2[j].x;
-                SB[j >> 1][j & 1] = v2[j].y;
-            }
-        } else {
-            gather8v(noisy_r, corner_of(kb), voff, a);
-            gather8v(noisy_r, corner_of(kb + 1), voff, b);
-#pragma unroll
-            for (int kl = 0; kl < KQ; kl += 2) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-                gather8v(basic_r, corner_of(kb + kl), voff, a);
-                gather8v(basic_r, corner_of(kb + kl + 1), voff, b);
-                pair_fwd<false>(T, tb, hi, lo, v2);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
-                    S[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-                if (kl + 2 < KQ) {
-                    gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
-                    gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
-                }
-                pair_fwd<false>(T, tb, hi, lo, v2);
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    SB[j >> 1][2 * kl + (j & 1)] = v2[j].x;
-                    SB[j >> 1][2 * kl + 2 + (j & 1)] = v2[j].y;
-                }
-            }
-        }
-
-        float sw = 0.0f;
-        f2 approx[NP];
-        wiener_quarter_local<KQ>(S, SB, sigma2, sw, approx);
-        f2 top[4];
-        if (K > 1) {
-            // publish: my transpose buffer is free (forward transforms done; every team mate
-            // acknowledged the previous exchange before my last inverse transforms started)
-#pragma unroll
-            for (int jp = 0; jp < NP; jp++) tb[jp * 64 + lane] = approx[jp];
-            tb[NP * 64 + lane] = mk2(sw, 0.0f);
-            raise_flag(sync + wave, seq, lane);
-            // wait for the team, then read its approximations plane pair by plane pair (member
-            // order; mine from registers) -- eight float2 live at a time instead of thirty-two
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-                if (m < A && m != member) wait_flag(sync + team0 + m, seq, lane);
-            auto from = [&](int m, int idx) -> f2 {
-                return m == member ? approx[idx] : team_tb[(size_t)m * (C::TBW / 2) + idx * 64 + lane];
-            };
-            // weight statistic: the members' local sums in member order, then the top levels
-            {
-                const float own = sw;
-                auto stat = [&](int m) -> float {
-                    return m == member ? own : team_tb[(size_t)m * (C::TBW / 2) + NP * 64 + lane].x;
-                };
-                sw = stat(0);
-                sw += stat(1);
-                if (A > 2) {
-                    sw += stat(2);
-                    sw += stat(3);
-                }
-            }
-            if (A == 2) {
-#pragma unroll
-                for (int jp = 0; jp < 4; jp++) {
-                    const f2 a0 = from(0, jp), a1 = from(1, jp), b0 = from(0, 4 + jp), b1 = from(1, 4 + jp);
-                    f2 t0 = (a0 + a1) * HAAR_C, t1 = (a0 - a1) * HAAR_C;
-                    const f2 u0 = (b0 + b1) * HAAR_C, u1 = (b0 - b1) * HAAR_C;
-                    t0 = wiener_w(u0, sigma2, sw) * t0;
-                    t1 = wiener_w(u1, sigma2, sw) * t1;
-                    top[jp] = member ? (t0 - t1) * HAAR_C : (t0 + t1) * HAAR_C;
-                }
-            } else {
-#pragma unroll
-                for (int jp = 0; jp < 4; jp++) {
-                    const f2 a0 = from(0, jp), a1 = from(1, jp), a2 = from(2, jp), a3 = from(3, jp);
-                    const f2 b0 = from(0, 4 + jp), b1 = from(1, 4 + jp), b2 = from(2, 4 + jp), b3 = from(3, 4 + jp);
-                    // forward: (0,1), (2,3), then the two sums -- the oracle's recursion
-                    const f2 s01 = (a0 + a1) * HAAR_C, s23 = (a2 + a3) * HAAR_C;
-                    f2 d01 = (a0 - a1) * HAAR_C, d23 = (a2 - a3) * HAAR_C;
-                    f2 ss = (s01 + s23) * HAAR_C, dd = (s01 - s23) * HAAR_C;
-                    const f2 t01 = (b0 + b1) * HAAR_C, t23 = (b2 + b3) * HAAR_C;
-                    const f2 e01 = (b0 - b1) * HAAR_C, e23 = (b2 - b3) * HAAR_C;
-                    const f2 tt = (t01 + t23) * HAAR_C, ee = (t01 - t23) * HAAR_C;
-                    ss = wiener_w(tt, sigma2, sw) * ss;
-                    dd = wiener_w(ee, sigma2, sw) * dd;
-                    d01 = wiener_w(e01, sigma2, sw) * d01;
-                    d23 = wiener_w(e23, sigma2, sw) * d23;
-                    // inverse, my member only
-                    const f2 r01 = (ss + dd) * HAAR_C, r23 = (ss - dd) * HAAR_C;
-                    const f2 lo2 = member < 2 ? r01 : r23, de = member < 2 ? d01 : d23;
-                    top[jp] = (member & 1) ? (lo2 - de) * HAAR_C : (lo2 + de) * HAAR_C;
-                }
-            }
-            cbar();
-            raise_flag(sync + HNW + wave, seq, lane);          // my team mates may reuse their buffers
-        } else {
-#pragma unroll
-            for (int jp = 0; jp < 4; jp++) top[jp] = wiener_w(approx[4 + jp], sigma2, sw) * approx[jp];
-        }
-        quarter_unshrink_local<KQ>(S, top);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sw += __shfl_xor(sw, off);
-        const float w = 1.0f / (sigma2 * (sw > 1.0f ? sw : 1.0f));
-        float ww[8];
-#pragma unroll
-        for (int y = 0; y < 8; y++) ww[y] = w * win_g[(hi * 8 + y) * 8 + lo];
-        if (lane >= kb && lane < kb + KQ) atomicAdd(cvol + (size_t)my_corner, w);
-
-        const int my_slot0 = (rz + my_dz + 5 + HNPL) % HNPL;
-        const int my_yx = (ry + my_dy - tg.y0) * REG + (rx + my_dx - tg.x0);
-        // every team mate must have read my approximations before the inverse transposes overwrite them
-        if (K > 1) {
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-                if (m < A && m != member) wait_flag(sync + HNW + team0 + m, seq, lane);
-        }
-        auto gate = [&](int k) {                   // per-block ring gate: see process_half_group
-            const int t = __builtin_amdgcn_readlane(my_dz, k) + 7;
-            const int need = layer + 1 - (HNPL - 5 - t + 3) / 4;
-            if (seen < need) {
-                cbar();
-                int v = 0;
-                if (lane == 0) {
-                    while ((v = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
-                        __builtin_amdgcn_s_sleep(8);
-                }
-                seen = __builtin_amdgcn_readfirstlane(v);
-                cbar();
-            }
-        };
-        auto ring_off = [&](int k) -> int {
-            int slot = __builtin_amdgcn_readlane(my_slot0, k) + hi;
-            slot -= slot >= HNPL ? HNPL : 0;
-            return slot * HPS + __builtin_amdgcn_readlane(my_yx, k) + lo;
-        };
-        auto ring_add = [&](int off, const f2 (&v)[8], int comp) {
-#pragma unroll
-            for (int y = 0; y < 8; y++)
-                __hip_atomic_fetch_add(ring + off + y * REG, (double)(ww[y] * (comp ? v[y].y : v[y].x)),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        if constexpr (KQ >= 4 && EXABM4D_X2INV) {
-            f2 w2[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                v2[j] = mk2(S[j >> 1][(j & 1)], S[j >> 1][2 + (j & 1)]);
-                w2[j] = mk2(S[j >> 1][4 + (j & 1)], S[j >> 1][6 + (j & 1)]);
-            }
-            pair_inv_x2<false>(T, tb, hi, lo, v2, w2);
-            gate(kb);
-            ring_add(ring_off(kb), v2, 0);
-            gate(kb + 1);
-            ring_add(ring_off(kb + 1), v2, 1);
-            gate(kb + 2);
-            ring_add(ring_off(kb + 2), w2, 0);
-            gate(kb + 3);
-            ring_add(ring_off(kb + 3), w2, 1);
-        } else {
-#pragma unroll
-            for (int kl = 0; kl < KQ; kl += 2) {
-                constexpr bool two = KQ > 1;
-                const int kl2 = two ? kl + 1 : kl;
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
-                pair_inv<false>(T, tb, hi, lo, v2);
-                gate(kb + kl);
-                ring_add(ring_off(kb + kl), v2, 0);
-                if constexpr (two) {
-                    gate(kb + kl2);
-                    ring_add(ring_off(kb + kl2), v2, 1);
-                }
-            }
-        }
-    };
-    if (active) {
-        switch (KQ) {
-            case 4: body(std::integral_constant<int, 4>{}); break;
-            case 2: body(std::integral_constant<int, 2>{}); break;
-            default: body(std::integral_constant<int, 1>{}); break;
-        }
-    } else {
-        // an idle member still reports, and like everybody else only once the layers whose planes
-        // this layer re-uses have been retired (see process_half_group)
-        if (lane == 0) {
-            while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < layer - 2)
-                __builtin_amdgcn_s_sleep(8);
-        }
-        cbar();
-    }
-    const int closer = (__hip_atomic_fetch_add(cnt + (layer & (HNCNT - 1)), lane == 0 ? 1 : 0, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == target) ? 1 : 0;
-    return __builtin_amdgcn_readfirstlane(closer) != 0;
-}
-
-__global__ __launch_bounds__(QuadCfg::NW * 64) void stage_quad_kernel(
-    const float* __restrict__ noisy_all, const float* __restrict__ basic_all,
-    const uint32_t* __restrict__ keys_all, VolGeom g, HalfTable T, const float* __restrict__ win_g,
-    float sigma2, float* __restrict__ num_all, float* __restrict__ cvol_all, int tiles_x, int layers_per_chunk) {
-    using C = QuadCfg;
-    constexpr int HNW = C::NW, HNPL = C::NPL, HPS = C::PS, HTY = C::TY, HTX = C::TX, NT = HNW / 4;
-    extern __shared__ __align__(16) float lds[];
-    ring_t* ring = reinterpret_cast<ring_t*>(lds);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    f2* tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + wave * C::TBW);
-    f2* team_tb = reinterpret_cast<f2*>(lds + 2 * HNPL * HPS + (wave & ~3) * C::TBW);
-    int* lock = reinterpret_cast<int*>(lds + 2 * HNPL * HPS + HNW * C::TBW);
-    int* sync = lock + 4;
-    int* cnt = sync + 2 * HNW;
-
-    const size_t voff = (size_t)blockIdx.z * (size_t)g.nvox;
-    const float* __restrict__ noisy = noisy_all + voff;
-    const float* __restrict__ basic = basic_all + voff;
-    float* __restrict__ num = num_all + voff;
-    float* __restrict__ cvol = cvol_all + voff;
-    const uint32_t* __restrict__ keys = keys_all + (size_t)blockIdx.z * (size_t)g.nref * MAXG;
-    const size_t sy = (size_t)g.nx, sz = (size_t)g.nx * (size_t)g.ny;
-
-    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int iy0 = HTY * ty, ix0 = HTX * tx;
-    TileGeom tg;
-    tg.nry = min(HTY, g.gy - iy0);
-    tg.nrx = min(HTX, g.gx - ix0);
-    tg.y0 = grid_pos(iy0, g.ay, g.ny) - RAD;
-    tg.x0 = grid_pos(ix0, g.ax, g.nx) - RAD;
-    const int nrefs = tg.nry * tg.nrx;
-    const int izb = blockIdx.y * layers_per_chunk;
-    const int ize = min(g.gz, izb + layers_per_chunk);
-
-    for (int i = threadIdx.x; i < 2 * HNPL * HPS; i += HNW * 64) lds[i] = 0.0f;
-    if (threadIdx.x < 4 + 2 * HNW + HNCNT) lock[threadIdx.x] = 0;
-    __syncthreads();
-
-    const int teamid = wave >> 2;
-    int seq = 0, seen = 0;
-    const Dct7& tab = T;
-    for (int iz = izb; iz < ize; iz++) {
-        const int layer = iz - izb;
-        const int z0 = grid_pos(iz, g.az, g.nz);
-        // groups go round the teams, one team further every layer, while every team has a group in
-        // every layer (layers must complete in order: see stage_half_kernel)
-        const int rot = nrefs >= NT ? layer % NT : 0;
-        for (int r = (teamid + rot) % NT; r < nrefs; r += NT) {
-            const int jy = r / tg.nrx, jx = r - jy * tg.nrx;
-            const int iy = iy0 + jy, ix = ix0 + jx;
-            const int ry = grid_pos(iy, g.ay, g.ny), rx = grid_pos(ix, g.ax, g.nx);
-            const uint32_t* kk = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
-#if EXABM4D_PRIO
-            {
-                int f = __hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                f = __builtin_amdgcn_readfirstlane(f);
-                if (layer <= f)
-                    __builtin_amdgcn_s_setprio(1);
-                else
-                    __builtin_amdgcn_s_setprio(0);
-            }
-#endif
-            const bool closer = process_quad_group(noisy, basic, kk, z0, ry, rx, tg, sy, sz, tab, win_g, sigma2,
-                                                   ring, cvol, tb, team_tb, lock, sync, cnt, wave, seq, seen,
-                                                   layer, 4 * nrefs, lane, g.nvox);
-            if (closer) {
-                if (lane == 0)
-                    __hip_atomic_store(cnt + (layer & (HNCNT - 1)), 0, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (lane == 0) {
-                    while (__hip_atomic_load(lock + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != layer)
-                        __builtin_amdgcn_s_sleep(2);
-                }
-                cbar();
-                if (iz + 1 < ize) {
-                    const int zn = grid_pos(iz + 1, g.az, g.nz);
-                    for (int z = z0 - RAD; z < zn - RAD; z++) flush_num_plane<C>(ring, num, z, tg, g, lane);
-                }
-                cbar();
-                if (lane == 0)
-                    __hip_atomic_store(lock + 1, layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                cbar();
-            }
-        }
-    }
-    __syncthreads();
-    if (ize > izb) {
-        const int base = grid_pos(ize - 1, g.az, g.nz) - RAD;
-        for (int z = base + wave; z < base + HNPL; z += HNW) flush_num_plane<C>(ring, num, z, tg, g, lane);
-    }
-}
-
 // (noisy, basic) -> float2 volume for the Wiener kernel's gathers
 __global__ __launch_bounds__(256) void interleave_pair_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               f2* __restrict__ out, size_t n) {
@@ -1930,122 +1032,55 @@ __global__ __launch_bounds__(256) void interleave_pair_kernel(const float* __res
         }
     }
 }
-int g_stage_pairvol = 1;     // exabm4d_set_option("stage_pairvol"): Wiener gathers from an interleaved (noisy, basic) volume
-
-int g_stage_quads = EXABM4D_WIE_QUADS;   // exabm4d_set_option("stage_quads"): Wiener stage on teams of four waves
-
-constexpr int NW_HT = 4;
-constexpr int NW_WIE = 4;
-int g_stage_chunks = 0;      // exabm4d_set_option("stage_chunks"): z chunks of the stage kernels, 0 = automatic
-// exabm4d_set_option("stage_strip"): the two-waves-per-group kernels walk their tile columns in strips of n
-// tile rows, column-major inside a strip (0 = raster): the 32 columns an XCD marches together form a patch
-// instead of a row, their gathers share more cache lines.  1024^3, A/B/A/B on one box: hard threshold
-// 161.5 -> 160.8 ms, Wiener 222.0 -> 220.1 ms with strips of 3 (2: about the same; 4: slower than raster).
-int g_stage_strip = 3;
-
+// One collaborative-filtering stage (basic == NULL: hard threshold; else Wiener).  Adds the numerator
+// terms to `num` (int64, units of 2^(43 - E) as qscale[2 b] says for volume b) and every block's weight
+// rint(u 2^40) to its corner voxel in `cw`; the caller zeroes both and turns cw into the denominator
+// (launch_den_*).  `pair`: 2 n floats of scratch for the Wiener stage's interleaved (noisy, basic)
+// volume, or NULL; pair_ready: the caller has filled it.
 hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* keys,
                         const VolGeom& g, int batch, const float* dct64, const float* win_dev,
-                        float thr, float sigma2, float* num, float* den, hipStream_t stream,
-                        int wave_pairs, const float* win1d, float* cwork, int den_overwrite, float* pair,
+                        float thr, float sigma2, const double* qscale, long long* num,
+                        unsigned long long* cw, hipStream_t stream, const StageOpts& opt, float* pair,
                         int pair_ready) {
     DctTable T;
     for (int i = 0; i < 64; i++) T.d[i] = dct64[i];
-    const int tiles_y = (g.gy + TILE_R - 1) / TILE_R, tiles_x = (g.gx + TILE_R - 1) / TILE_R;
-    // Split z into chunks when there are too few tiles to fill 256 CUs (small volumes / patches).
-    const long long tiles = (long long)tiles_y * tiles_x * batch;
-    int chunks = (int)((1024 + tiles - 1) / tiles);
-    if (chunks < 1) chunks = 1;
-    if (chunks > g.gz) chunks = g.gz;
-    const int lpc = (g.gz + chunks - 1) / chunks;
-    chunks = (g.gz + lpc - 1) / lpc;
-    dim3 grid((unsigned)(tiles_y * tiles_x), (unsigned)chunks, (unsigned)batch);
-    if (wave_pairs) {
-        // The two-waves-per-group kernels collect the numerator in `num` and the weight of every
-        // block on its corner voxel in cwork[0 .. n); den += C (*) win follows in three 8-tap passes
-        // (cwork[n .. 2n) is the ping-pong buffer).
-        const size_t n = (size_t)g.nvox * (size_t)batch;
-        hipError_t e = hipMemsetAsync(cwork, 0, n * sizeof(float), stream);
-        if (e != hipSuccess) return e;
-        Dct7 HT;
-        if (!make_dct7(T, HT)) return hipErrorInvalidValue;    // the table lost its symmetry
-        auto launch = [&](auto wiener_c) -> hipError_t {
-            constexpr bool W = decltype(wiener_c)::value;
-            using C = HalfCfg<W>;
-            const int hty = (g.gy + C::TY - 1) / C::TY, htx = (g.gx + C::TX - 1) / C::TX;
-            const long long htiles = (long long)hty * htx * batch;
-            // z chunks: at least ~4 work items per CU, and -- while a chunk keeps >= 16 layers, so
-            // that its ring start-up and final flush stay small -- about 128 per CU (a 1024^3
-            // volume has few tile columns per CU and the last ones leave most of the chip idle;
-            // measured flat between 2 and 8 chunks at 1024^3).
-            int hchunks = (int)((1024 + htiles - 1) / htiles);
-            const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
-            if (hchunks < fine) hchunks = fine;
-            if (g_stage_chunks > 0) hchunks = g_stage_chunks;
-            if (hchunks < 1) hchunks = 1;
-            if (hchunks > g.gz) hchunks = g.gz;
-            const int hlpc = (g.gz + hchunks - 1) / hchunks;
-            hchunks = (g.gz + hlpc - 1) / hlpc;
-            const dim3 hgrid((unsigned)(hty * htx), (unsigned)hchunks, (unsigned)batch);
-            const size_t lds = sizeof(float) * C::LDS_FLOATS;
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<W>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (err != hipSuccess) return err;
-            const f2* pairvol = nullptr;
-            if (W && pair && g_stage_pairvol && (pair_ready || (n % 4) == 0)) {
-                f2* pv = reinterpret_cast<f2*>(pair);
-                if (!pair_ready)
-                    hipLaunchKernelGGL(interleave_pair_kernel, dim3(65536), dim3(256), 0, stream, noisy, basic, pv, n);
-                pairvol = pv;
-            }
-            hipLaunchKernelGGL(stage_half_kernel<W>, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys,
-                               g, HT, win_dev, thr, sigma2, num, cwork, htx, hlpc, pairvol, g_stage_strip);
-            return hipGetLastError();
-        };
-        auto launch_quads = [&]() -> hipError_t {
-            using C = QuadCfg;
-            const int hty = (g.gy + C::TY - 1) / C::TY, htx = (g.gx + C::TX - 1) / C::TX;
-            const long long htiles = (long long)hty * htx * batch;
-            int hchunks = (int)((1024 + htiles - 1) / htiles);
-            const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
-            if (hchunks < fine) hchunks = fine;
-            if (g_stage_chunks > 0) hchunks = g_stage_chunks;
-            if (hchunks < 1) hchunks = 1;
-            if (hchunks > g.gz) hchunks = g.gz;
-            const int hlpc = (g.gz + hchunks - 1) / hchunks;
-            hchunks = (g.gz + hlpc - 1) / hlpc;
-            const dim3 hgrid((unsigned)(hty * htx), (unsigned)hchunks, (unsigned)batch);
-            const size_t lds = sizeof(float) * C::LDS_FLOATS;
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_quad_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (err != hipSuccess) return err;
-            hipLaunchKernelGGL(stage_quad_kernel, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys, g, HT,
-                               win_dev, sigma2, num, cwork, htx, hlpc);
-            return hipGetLastError();
-        };
-        e = basic ? (g_stage_quads ? launch_quads() : launch(std::true_type{})) : launch(std::false_type{});
-        if (e != hipSuccess) return e;
-        if (den_overwrite == 2)       // the pipelines fuse the z pass into their normalisation kernel
-            return launch_den_xy_from_corners(cwork, cwork + n, g.nz, g.ny, g.nx, batch, win1d, stream);
-        return launch_den_from_corners(cwork, cwork + n, den, g.nz, g.ny, g.nx, batch, win1d,
-                                       den_overwrite, stream);
-    } else if (basic) {
-        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_WIE * 2 * TBUF + 4);
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&stage_tile_kernel<true, NW_WIE>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((stage_tile_kernel<true, NW_WIE>), grid, dim3(NW_WIE * 64), lds, stream,
-                           noisy, basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, lpc);
-    } else {
-        const size_t lds = sizeof(float) * (2 * NPL * PS + NW_HT * 2 * TBUF + 4);
-        hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&stage_tile_kernel<false, NW_HT>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((stage_tile_kernel<false, NW_HT>), grid, dim3(NW_HT * 64), lds, stream,
-                           noisy, basic, keys, g, T, win_dev, thr, sigma2, num, den, tiles_x, lpc);
-    }
-    return hipGetLastError();
+    const size_t n = (size_t)g.nvox * (size_t)batch;
+    Dct7 HT;
+    if (!make_dct7(T, HT)) return hipErrorInvalidValue;    // the table lost its symmetry
+    auto launch = [&](auto wiener_c) -> hipError_t {
+        constexpr bool W = decltype(wiener_c)::value;
+        using C = HalfCfg<W>;
+        const int hty = (g.gy + C::TY - 1) / C::TY, htx = (g.gx + C::TX - 1) / C::TX;
+        const long long htiles = (long long)hty * htx * batch;
+        // z chunks: at least ~4 work items per CU, and -- while a chunk keeps >= 16 layers, so
+        // that its ring start-up and final flush stay small -- about 128 per CU (a 1024^3
+        // volume has few tile columns per CU and the last ones leave most of the chip idle;
+        // measured flat between 2 and 8 chunks at 1024^3).
+        int hchunks = (int)((1024 + htiles - 1) / htiles);
+        const int fine = (int)std::min<long long>((32768 + htiles - 1) / htiles, g.gz / 16);
+        if (hchunks < fine) hchunks = fine;
+        if (opt.chunks > 0) hchunks = opt.chunks;
+        if (hchunks < 1) hchunks = 1;
+        if (hchunks > g.gz) hchunks = g.gz;
+        const int hlpc = (g.gz + hchunks - 1) / hchunks;
+        hchunks = (g.gz + hlpc - 1) / hlpc;
+        const dim3 hgrid((unsigned)(hty * htx), (unsigned)hchunks, (unsigned)batch);
+        const size_t lds = sizeof(float) * C::LDS_FLOATS;
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&stage_half_kernel<W>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        const f2* pairvol = nullptr;
+        if (W && pair && opt.pairvol && (pair_ready || (n % 4) == 0)) {
+            f2* pv = reinterpret_cast<f2*>(pair);
+            if (!pair_ready)
+                hipLaunchKernelGGL(interleave_pair_kernel, dim3(65536), dim3(256), 0, stream, noisy, basic, pv, n);
+            pairvol = pv;
+        }
+        hipLaunchKernelGGL(stage_half_kernel<W>, hgrid, dim3(C::NW * 64), lds, stream, noisy, basic, keys,
+                           g, HT, win_dev, thr, sigma2, qscale, num, cw, htx, hlpc, pairvol, opt.strip);
+        return hipGetLastError();
+    };
+    return basic ? launch(std::true_type{}) : launch(std::false_type{});
 }
 
 #ifdef EXABM4D_STAMPS

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EXABM4D_VERSION 302 /* 0.3.2: + exabm4d_blockmatch_plan, option "stage_strip"; 0.3.1: + exabm4d_denoise_chunked_u16_host, options "bm_carry" / "bm_xcd_mode"; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
+#define EXABM4D_VERSION 400 /* 0.4.0 (round 4): order-independent aggregation -- exabm4d_stage_dev takes data_exp and WRITES num / den, options "stage_pairs" / "stage_quads" / "fuse_den_z" are gone, the stage / block-matching options are per context; 0.3.2: + exabm4d_blockmatch_plan, option "stage_strip"; 0.3.1: + exabm4d_denoise_chunked_u16_host, options "bm_carry" / "bm_xcd_mode"; 0.3.0: EXAC v2 coder, exabm4d_codec_decode_dev takes in_bytes (round 3) */
 
 typedef enum exabm4d_status {
     EXABM4D_OK = 0,
@@ -111,17 +111,13 @@ int exabm4d_default_params(exabm4d_params* p);
 /* Diagnostic switches. "force_generic_bm" = 1 routes every reference block through the
  * one-wave-per-block matching kernel (normally used only for grid points that are not a
  * multiple of 4); the parity tests use it to check the two kernels against each other.
- * "stage_pairs" = 0 selects the one-wave-per-group stage kernels instead of the default
- * two-waves-per-group ones (same arithmetic; kept as a cross-check).
  * "bm_guarded_copy" = 1 makes exabm4d_blockmatch_dev match on a copy of the volume inside the
  * library's scratch allocation, the way the exabm4d_denoise_* pipelines do (x-edge tiles then
  * stream their planes by LDS-DMA without clamping); for the parity tests.
  * Round 3: "codec_version" = 1 | 2 (default 2): the EXAC format exabm4d_codec_encode_dev writes (the
  * option is per context, not per call: do not switch it from two threads of one context);
- * "fuse_den_z" = 0 runs the denominator's z pass and the normalisation as separate kernels (default 1:
- * fused, bit-identical); "stage_pairvol" = 0 makes the Wiener kernel gather its two
- * volumes separately (default 1: one interleaved volume); "stage_quads" = 1 runs the
- * Wiener stage on teams of four waves per group (default 0: measured slower);
+ * "stage_pairvol" = 0 makes the Wiener kernel gather its two volumes separately (default 1: one
+ * interleaved volume);
  * "bm_int" = 0 keeps the uint16 pipelines' stage-1 matching on the float kernel; "stage_chunks",
  * "chunk_budget_mb", "profile": z chunks of the stage kernels (0 = automatic), scratch budget of the
  * chunk-local mode, per-phase HIP events for exabm4d_profile_read.  "bm_carry" = 0 | 1 | 2 (default 1):
@@ -130,9 +126,8 @@ int exabm4d_default_params(exabm4d_params* p);
  * enough, 2: wherever a column has two tiles; needs 744 KB of device memory per tile column, allocated on
  * first use; tables are identical); "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
  * block matching; "stage_strip" = 0 | n (default 3): tile-column order of the stage
- * kernels (0 = raster, n = strips of n tile rows; same results up to the order of the global fp32 adds).
- * "stage_pairvol", "stage_quads", "stage_chunks", "stage_strip", "bm_carry" and "bm_xcd_mode" are
- * process-wide. */
+ * kernels (0 = raster, n = strips of n tile rows; the same results, bit for bit: the sums are integers).
+ * Every option belongs to the context it is set on (round 4; rounds 1-3 kept some in process globals). */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
 /* With option "profile" = 1 every exabm4d_denoise_* call brackets each of its kernel launches
  * with HIP events on the context's stream.  exabm4d_profile_read waits for the last call and
@@ -203,10 +198,18 @@ int exabm4d_match_decode(const uint32_t* keys16, int rz, int ry, int rx, int ny,
                          int64_t* idx, float* dist, int* count);
 /* Collaborative filtering + aggregation.  basic == NULL: hard-threshold stage on `noisy`;
  * basic != NULL: Wiener stage (groups of `noisy` and `basic` at the same positions).
- * num/den ([batch][nz][ny][nx] fp32) are ADDED to; zero them first (exabm4d_memset). */
+ * The sums over blocks are 64-bit integers, so the result does not depend on the order
+ * the GPU adds in: num[batch][nz][ny][nx] = fl32(NUM 2^(E - 43)) with NUM = sum of
+ * rint(est * fl32(u win) * 2^(43 - E)), den = fl32(CW 2^-40) convolved with the separable Kaiser window,
+ * CW = sum of rint(u 2^40) on block corners, u = 1 / max(N_kept, 1) resp. 1 / max(sum W^2, 1).  Both are
+ * WRITTEN (round 4; rounds 1-3 added into them).  data_exp = E: EXABM4D_DATA_EXP_AUTO takes, per volume of
+ * the batch, the exponent with max |noisy| < 2^E (what exabm4d_denoise_f32_* do); a caller that shards one
+ * volume passes one value for all shards (the uint16 pipelines use EXABM4D_DATA_EXP_U16 = 17). */
+#define EXABM4D_DATA_EXP_AUTO INT32_MIN
+#define EXABM4D_DATA_EXP_U16 17
 int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
                       const uint32_t* keys, int nz, int ny, int nx, int batch, float sigma,
-                      const exabm4d_params* p, float* num, float* den);
+                      const exabm4d_params* p, int data_exp, float* num, float* den);
 /* out = num/den, then clamp to [clip_lo, clip_hi] when clip_lo <= clip_hi (np.clip,
  * data_handling.py:333); pass clip_lo > clip_hi for no clamp. */
 int exabm4d_normalize_dev(exabm4d_ctx* ctx, const float* num, const float* den, float* out,
@@ -227,7 +230,9 @@ int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int n
                             int batch, float sigma, const exabm4d_params* p, int stages,
                             float clip_lo, float clip_hi);
 /* uint16 in -> (float)in - offset -> BM4D -> + offset -> clamp [0,65535] -> rint -> uint16.
- * (read_counts + bm4d + clip + the rint/uint16 cast of IntensityTransform.inverse.) */
+ * (read_counts + bm4d + clip + the rint/uint16 cast of IntensityTransform.inverse.)  |offset| <= 65536.
+ * The result is a deterministic function of the input: two calls, the chunked / streamed forms on
+ * identical padded chunks and the oracle give the same uint16 values. */
 int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
                             int nx, int batch, float sigma, float offset, const exabm4d_params* p,
                             int stages);

@@ -1,8 +1,10 @@
 """GPU parity: BM4D kernels (through the C-ABI) vs the CPU oracle on identical inputs.
 
-Bars (BASELINE.json north_star): match tables bit-exact; estimates within fp32 tolerance
-(aggregation uses fp32 atomics, whose order is unspecified) and PSNR delta < 0.01 dB;
-uint16 outputs equal except where an fp32 ulp moves a value across a .5 boundary.
+Bars: since round 4 EVERYTHING is bit-exact.  Match tables always were; the aggregation's sums are
+64-bit integers now and the Wiener weights use a bit-defined reciprocal (3.7), so the
+stage outputs, the fp32 estimates and the uint16 volumes equal the oracle's bit for bit, whatever the
+order in which waves, workgroups and launches add (rounds 1-3: fp32 tolerance, uint16 within a count,
+2-4 counts on rare voxels after a changed stage-2 group).
 """
 import numpy as np
 import pytest
@@ -89,34 +91,37 @@ def test_blockmatch_wiener_threshold(ctx, oracle):
     np.testing.assert_array_equal(got, want)
 
 
-def _stage_gpu(ctx, noisy, keys, sigma, basic=None):
+def _stage_gpu(ctx, noisy, keys, sigma, basic=None, data_exp=None):
     d_noisy = ctx.to_device(noisy)
     d_basic = ctx.to_device(basic) if basic is not None else None
     d_keys = ctx.to_device(keys)
-    d_num = ctx.alloc(noisy.nbytes).zero()
-    d_den = ctx.alloc(noisy.nbytes).zero()
-    ctx.stage(d_noisy, d_basic, d_keys, noisy.shape, sigma, d_num, d_den)
-    ctx.sync()
-    return d_num.download(noisy.shape, np.float32), d_den.download(noisy.shape, np.float32)
+    d_num = ctx.alloc(noisy.nbytes).fill(0xFF)        # the call WRITES both (NaN patterns must not survive)
+    d_den = ctx.alloc(noisy.nbytes).fill(0xFF)
+    try:
+        ctx.stage(d_noisy, d_basic, d_keys, noisy.shape, sigma, d_num, d_den, data_exp=data_exp)
+        ctx.sync()
+        return d_num.download(noisy.shape, np.float32), d_den.download(noisy.shape, np.float32)
+    finally:
+        for b in (d_noisy, d_basic, d_keys, d_num, d_den):
+            if b is not None:
+                b.free()
 
 
-def _assert_close_estimates(got, want, sigma):
-    diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
-    tol = 1e-4 * sigma + 1e-5 * np.abs(want)
-    frac_bad = float(np.mean(diff > tol))
-    assert frac_bad < 1e-3, f"{frac_bad:.2e} of voxels outside fp32 tolerance, max {diff.max()}"
-    assert diff.max() < 0.05 * sigma
+def _assert_stage_is_the_oracles(ctx, oracle, noisy, keys, basic=None, port=False, data_exp=None):
+    num_w, den_w = oracle.stage(noisy, keys, SIGMA, basic=basic, port=port, data_exp=data_exp)
+    num_g, den_g = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic, data_exp=data_exp)
+    assert np.all(den_g > 0)
+    np.testing.assert_array_equal(den_g, den_w)
+    np.testing.assert_array_equal(num_g, num_w)
+    return num_g, den_g
 
 
 @pytest.mark.parametrize("shape", [(40, 44, 48), (30, 37, 41)])
 def test_hard_threshold_stage(ctx, oracle, shape):
     noisy, _ = synth_volume(shape, seed=11)
     keys = oracle.blockmatch(noisy, SIGMA, 3.0)
-    num_w, den_w = oracle.stage(noisy, keys, SIGMA)
-    num_g, den_g = _stage_gpu(ctx, noisy, keys, SIGMA)
-    assert np.all(den_g > 0)
-    np.testing.assert_allclose(den_g, den_w, rtol=2e-5)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    _assert_stage_is_the_oracles(ctx, oracle, noisy, keys)
+    _assert_stage_is_the_oracles(ctx, oracle, noisy, keys, data_exp=17)       # the uint16 pipelines' unit
 
 
 def _mixed_volume(shape, seed):
@@ -130,62 +135,47 @@ def _mixed_volume(shape, seed):
     return vol
 
 
-def test_half_group_kernel_equals_single_wave_kernel(ctx, oracle):
-    """The two-waves-per-group hard-threshold kernel against the one-wave-per-group kernel on a
-    volume large enough that tiles march over several z-layers, with every group size present
-    (one-block groups leave the second wave of a pair idle) -- and both against the oracle."""
-    shape = (48, 384, 400)          # 800 tiles -> two z-chunks of six layers each
+def test_marching_tiles_with_every_group_size_equal_the_cpu_port(ctx, oracle):
+    """A volume large enough that tiles march over several z-layers and z chunks, with every group size
+    present (one-block groups leave the second wave of a pair idle): both stage kernels against the CPU
+    port (bit-identical to the oracle, tests/test_oracle_bm4d.py) on the WHOLE volume, bit for bit, and
+    twice in a row -- the second launch adds in another order."""
+    shape = (48, 192, 200)
     noisy = _mixed_volume(shape, 23)
     keys = _keys_gpu(ctx, noisy, SIGMA, 3.0)
     sizes = np.unique((keys != 0xFFFFFFFF).sum(axis=-1))
     assert sizes.min() <= 1 and sizes.max() == 16
-    ctx.set_option("stage_pairs", 0)
-    try:
-        num0, den0 = _stage_gpu(ctx, noisy, keys, SIGMA)
-    finally:
-        ctx.set_option("stage_pairs", 1)
-    num1, den1 = _stage_gpu(ctx, noisy, keys, SIGMA)
-    assert np.all(den1 > 0)
-    np.testing.assert_allclose(den1, den0, rtol=2e-5)
-    _assert_close_estimates(num1 / den1, num0 / den0, SIGMA)
-    sub = (slice(0, 32), slice(40, 88), slice(0, 48))          # oracle on a crop that has all regimes
-    crop = np.ascontiguousarray(noisy[sub])
-    kc = oracle.blockmatch(crop, SIGMA, 3.0)
-    num_w, den_w = oracle.stage(crop, kc, SIGMA)
-    num_g, den_g = _stage_gpu(ctx, crop, kc, SIGMA)
-    np.testing.assert_allclose(den_g, den_w, rtol=2e-5)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    a = _assert_stage_is_the_oracles(ctx, oracle, noisy, keys, port=True)
+    b = _stage_gpu(ctx, noisy, keys, SIGMA)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    basic = (noisy + np.random.default_rng(5).normal(0, 2.0, shape)).astype(np.float32)   # any second volume will do
+    _assert_stage_is_the_oracles(ctx, oracle, noisy, keys, basic=basic, port=True)
 
 
-def test_tall_ragged_volume_pairs_equal_single_wave_kernels(ctx):
+def test_tall_ragged_volume_every_launch_shape_gives_the_oracles_result(ctx, oracle):
     """Regression (round 2): tile columns that march over MANY layers in one z chunk, with edge
     tiles that hold fewer groups than the workgroup has wave pairs -- a pair without a group in a
     layer must not let a layer complete (and its ring planes be flushed) before the layer below.
-    The two-waves-per-group kernels against the one-wave-per-group kernels (one stage: same match
-    tables, only the order of the aggregation sums differs -> at most one count)."""
+    One chunk of 63 layers, the automatic chunking and 9 chunks: the CPU port's uint16 volume each time."""
     import bench
     shape = (253, 61, 57)
     vol = bench.synth_u16(shape, 7)
     vol[:40] = 0                                  # zero padding: every candidate matches
     vol[:, :, -9:] = 0
+    want = oracle.bm4d_u16(vol, SIGMA, 37.0, port=True)
     d_in = ctx.to_device(vol)
     d_out = ctx.alloc(vol.nbytes)
-    outs = []
-    ctx.set_option("stage_chunks", 1)             # one chunk: 63 layers per tile column
     try:
-        for pairs in (1, 0, 1):
-            ctx.set_option("stage_pairs", pairs)
-            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0, stages=1)
+        for chunks in (1, 0, 9):
+            ctx.set_option("stage_chunks", chunks)
+            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0)
             ctx.sync()
-            outs.append(d_out.download(shape, np.uint16).astype(np.int32))
+            np.testing.assert_array_equal(d_out.download(shape, np.uint16), want, err_msg=f"stage_chunks {chunks}")
     finally:
-        ctx.set_option("stage_pairs", 1)
         ctx.set_option("stage_chunks", 0)
         d_in.free()
         d_out.free()
-    for a in (outs[0], outs[2]):
-        d = np.abs(a - outs[1])
-        assert d.max() <= 1 and np.mean(d > 0) < 5e-3, (int(d.max()), int((d > 1).sum()))
 
 
 def test_wiener_stage(ctx, oracle):
@@ -193,10 +183,7 @@ def test_wiener_stage(ctx, oracle):
     noisy, _ = synth_volume(shape, seed=13)
     basic = oracle.bm4d(noisy, SIGMA, stages=1)
     keys = oracle.blockmatch(basic, SIGMA, 0.6)
-    num_w, den_w = oracle.stage(noisy, keys, SIGMA, basic=basic)
-    num_g, den_g = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic)
-    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    _assert_stage_is_the_oracles(ctx, oracle, noisy, keys, basic=basic)
 
 
 @pytest.mark.parametrize("stages", [1, 2])
@@ -205,22 +192,17 @@ def test_pipeline_f32_psnr(ctx, oracle, stages):
     noisy, clean = synth_volume(shape, seed=17)
     want = oracle.bm4d(noisy, SIGMA, stages=stages)
     got = ctx.denoise_f32_host(noisy, SIGMA, stages=stages)
+    np.testing.assert_array_equal(got, want)
     peak = float(clean.max() - clean.min())
-    p_w, p_g = psnr(want, clean, peak), psnr(got, clean, peak)
-    assert abs(p_w - p_g) < 0.01, (p_w, p_g)
-    assert p_g > psnr(noisy, clean, peak) + 8.0        # it actually denoises
-    assert psnr(got, want, peak) > 80.0
-    if stages == 1:
-        _assert_close_estimates(got, want, SIGMA)
+    assert psnr(got, clean, peak) > psnr(noisy, clean, peak) + 8.0        # it actually denoises
 
 
 def test_pipeline_batch_of_patches(ctx, oracle):
     """N independent 48^3 patches in one call == N single calls (precompute.py call pattern)."""
     vols = np.stack([synth_volume((48, 48, 48), seed=s)[0] for s in (1, 2, 3)])
     got = ctx.denoise_f32_host(vols, SIGMA, clip=(0.0, 65535.0))
-    for i in range(3):
-        want = np.clip(oracle.bm4d(vols[i], SIGMA), 0, 65535)
-        assert psnr(got[i], want, 1000.0) > 80.0
+    for i in range(3):       # (every volume of a batch gets its own numerator unit, like a single call)
+        np.testing.assert_array_equal(got[i], np.clip(oracle.bm4d(vols[i], SIGMA), 0, 65535))
 
 
 def test_pipeline_u16(ctx, oracle):
@@ -231,10 +213,10 @@ def test_pipeline_u16(ctx, oracle):
     d_out = ctx.alloc(vol.nbytes)
     ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0)
     ctx.sync()
-    got = d_out.download(shape, np.uint16)
-    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    assert d.max() <= 1
-    assert np.mean(d > 0) < 2e-3
+    np.testing.assert_array_equal(d_out.download(shape, np.uint16), want)
+    ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0)           # and again: a deterministic function of its input
+    ctx.sync()
+    np.testing.assert_array_equal(d_out.download(shape, np.uint16), want)
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 8), (8, 9, 12), (12, 8, 8), (9, 9, 9), (16, 8, 20),
@@ -246,7 +228,7 @@ def test_tiny_and_thin_volumes_full_pipeline(ctx, oracle, shape):
     for stages in (1, 2):
         want = oracle.bm4d(vol, SIGMA, stages=stages)
         got = ctx.denoise_f32_host(vol, SIGMA, stages=stages)
-        assert np.abs(got - want).max() < 0.05
+        np.testing.assert_array_equal(got, want)
 
 
 def test_bad_arguments_raise(ctx):
@@ -263,7 +245,7 @@ def test_bad_arguments_raise(ctx):
 def test_zero_padded_volume_and_small_groups(ctx, oracle):
     """Edge cases of the domain: a volume that is mostly zero padding (every candidate of a block
     ties at distance 0, aggregation sees all-zero groups), a bright block with few matches
-    (group sizes 1, 2, 4, 8 appear) -- match tables bit-exact, both stages within tolerance."""
+    (group sizes 1, 2, 4, 8 appear) -- match tables and both stages bit-exact."""
     rng = np.random.default_rng(23)
     vol = np.zeros((40, 36, 44), dtype=np.float32)
     vol[12:28, 10:26, 14:34] = rng.normal(300.0, SIGMA, (16, 16, 20)).astype(np.float32)
@@ -273,17 +255,11 @@ def test_zero_padded_volume_and_small_groups(ctx, oracle):
     np.testing.assert_array_equal(keys, want)
     counts = (want != 0xFFFFFFFF).sum(-1)
     assert counts.min() < 16 and counts.max() == 16
-    num_w, den_w = oracle.stage(vol, want, SIGMA)
-    num_g, den_g = _stage_gpu(ctx, vol, want, SIGMA)
-    np.testing.assert_allclose(den_g, den_w, rtol=2e-5)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
-    basic = oracle.normalize(num_w, den_w)
+    num_g, den_g = _assert_stage_is_the_oracles(ctx, oracle, vol, want)
+    basic = oracle.normalize(num_g, den_g)
     keys2 = oracle.blockmatch(basic, SIGMA, 0.6)
     np.testing.assert_array_equal(_keys_gpu(ctx, basic, SIGMA, 0.6), keys2)
-    num_w, den_w = oracle.stage(vol, keys2, SIGMA, basic=basic)
-    num_g, den_g = _stage_gpu(ctx, vol, keys2, SIGMA, basic=basic)
-    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    _assert_stage_is_the_oracles(ctx, oracle, vol, keys2, basic=basic)
 
 
 def test_batch_of_unaligned_volumes_stage1_u16(ctx, oracle):
@@ -297,9 +273,7 @@ def test_batch_of_unaligned_volumes_stage1_u16(ctx, oracle):
     ctx.sync()
     got = d_out.download(vols.shape, np.uint16)
     for i in range(2):
-        want = oracle.bm4d_u16(vols[i], SIGMA, 37.0, stages=1)
-        d = np.abs(got[i].astype(np.int32) - want.astype(np.int32))
-        assert d.max() <= 1 and np.mean(d > 0) < 2e-3
+        np.testing.assert_array_equal(got[i], oracle.bm4d_u16(vols[i], SIGMA, 37.0, stages=1))
 
 
 def test_other_sigma_and_profile(ctx, oracle):
@@ -309,11 +283,13 @@ def test_other_sigma_and_profile(ctx, oracle):
     small = (vol / np.float32(4000.0)).astype(np.float32)
     got = ctx.denoise_f32_host(small, SIGMA / 4000.0)
     want = oracle.bm4d(small, SIGMA / 4000.0)
-    assert psnr(got, want, float(small.max() - small.min())) > 80.0
+    np.testing.assert_array_equal(got, want)
+    big = (vol * np.float32(3.0e7)).astype(np.float32)         # ... and data far above the uint16 range (E = 38)
+    np.testing.assert_array_equal(ctx.denoise_f32_host(big, SIGMA * 3.0e7), oracle.bm4d(big, SIGMA * 3.0e7))
     p = nat.default_params(kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
     got = ctx.denoise_f32_host(vol, SIGMA, params=p)
     want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
-    assert psnr(got, want, 1000.0) > 80.0
+    np.testing.assert_array_equal(got, want)
 
 
 def _keys_u16(ctx, vol, sigma, c_match, batch=1):
@@ -366,8 +342,8 @@ def test_non_dyadic_offset_takes_the_float_kernel(ctx, oracle):
     fp32: voxel differences are no longer integers, so the integer matching kernel would not give
     the float kernel's tables.  The launcher must fall back to the float kernel for such offsets
     (offset * 128 not an integer): switching the integer path off changes nothing, and the result
-    is the oracle's (which always matches on the fp32 counts) within a count.  With a dyadic
-    offset the integer kernel does run, and its result is the float kernel's too."""
+    is the oracle's (which always matches on the fp32 counts).  With a dyadic offset the integer
+    kernel does run, and its result is the float kernel's too.  All of it bit for bit."""
     vol = synth_volume((40, 48, 64), seed=77, as_u16=True)[0]
 
     def run(offset, bm_int):
@@ -383,118 +359,21 @@ def test_non_dyadic_offset_takes_the_float_kernel(ctx, oracle):
 
     for offset in (36.73, 0.3, 100.5, 37.0):
         a, b = run(offset, 1), run(offset, 0)
-        d = np.abs(a.astype(np.int32) - b.astype(np.int32))
-        # same tables => same groups; only the aggregation's arrival order differs between runs
-        assert d.max() <= 1 and np.mean(d > 0) < 1e-3, (offset, int(d.max()), float(np.mean(d > 0)))
-        want = oracle.bm4d_u16(vol, SIGMA, offset)
-        d = np.abs(a.astype(np.int32) - want.astype(np.int32))
-        assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (offset, int(d.max()), float(np.mean(d > 0)))
+        np.testing.assert_array_equal(a, b, err_msg=f"offset {offset}: integer / float matching")
+        np.testing.assert_array_equal(a, oracle.bm4d_u16(vol, SIGMA, offset), err_msg=f"offset {offset}")
     # the gate itself, on the host side used by the slab driver
     from aind_exaspim_image_compression.distributed import offset_exact_in_fp32
     assert [offset_exact_in_fp32(o) for o in (0.0, 37.0, 100.5, 0.0078125, 36.73, 0.3, 70000.0)] == \
         [True, True, True, True, False, False, False]
 
 
-def test_quarter_group_wiener_kernel_equals_pairs_and_oracle(ctx, oracle):
-    """Round 3: the Wiener stage on teams of FOUR waves per group (stage_quad_kernel, an OPTION: it
-    measured 293 ms against 228 ms for the two-waves-per-group kernel at 1024^3 and is off by
-    default; groups of 16 /
-    8 / 4 give every member 4 / 2 / 1 blocks, groups of 2 and 1 leave members idle) against the
-    two-waves-per-group kernel and against the oracle: same match tables in, spectra bit-identical by
-    construction, estimates equal up to the order of the aggregation sums and of the weight
-    statistic.  A volume with every group size, tiles that march over several layers; then a tall
-    ragged one with edge tiles that hold fewer groups than the workgroup has teams."""
-    shape = (48, 384, 400)
-    noisy = _mixed_volume(shape, 31)
-    basic = (noisy + np.random.default_rng(5).normal(0, 2.0, shape)).astype(np.float32)   # any second volume will do
-    keys = _keys_gpu(ctx, basic, SIGMA, 3.0)          # (the admission bound only shapes the groups here)
-    sizes = np.unique((keys != 0xFFFFFFFF).sum(axis=-1))
-    assert sizes.min() <= 1 and sizes.max() == 16
-    res = {}
-    try:
-        for quads in (1, 0):
-            ctx.set_option("stage_quads", quads)
-            res[quads] = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic)
-    finally:
-        ctx.set_option("stage_quads", 0)
-    (num1, den1), (num0, den0) = res[1], res[0]
-    assert np.all(den1 > 0)
-    np.testing.assert_allclose(den1, den0, rtol=2e-5)
-    _assert_close_estimates(num1 / den1, num0 / den0, SIGMA)
-    sub = (slice(0, 32), slice(100, 148), slice(60, 108))       # oracle on a crop across the regimes
-    cn, cb = np.ascontiguousarray(noisy[sub]), np.ascontiguousarray(basic[sub])
-    kc = oracle.blockmatch(cb, SIGMA, 3.0)
-    num_w, den_w = oracle.stage(cn, kc, SIGMA, basic=cb)
-    ctx.set_option("stage_quads", 1)
-    try:
-        num_g, den_g = _stage_gpu(ctx, cn, kc, SIGMA, basic=cb)
-    finally:
-        ctx.set_option("stage_quads", 0)
-    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
-    # tall + ragged, one z chunk, both stages through the uint16 pipeline
-    import bench
-    shape = (253, 61, 57)
-    vol = bench.synth_u16(shape, 7)
-    vol[:40] = 0
-    vol[:, :, -9:] = 0
-    d_in, d_out = ctx.to_device(vol), ctx.alloc(vol.nbytes)
-    outs = []
-    ctx.set_option("stage_chunks", 1)
-    try:
-        for quads in (1, 0, 1):
-            ctx.set_option("stage_quads", quads)
-            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0, stages=2)
-            ctx.sync()
-            outs.append(d_out.download(shape, np.uint16).astype(np.int32))
-    finally:
-        ctx.set_option("stage_quads", 0)
-        ctx.set_option("stage_chunks", 0)
-        d_in.free()
-        d_out.free()
-    for a in (outs[0], outs[2]):
-        d = np.abs(a - outs[1])
-        assert d.max() <= 1 and np.mean(d > 0) < 5e-3, (int(d.max()), int((d > 1).sum()))
-
-
-@pytest.mark.parametrize("shape", [(40, 44, 48), (24, 31, 37), (16, 20, 22)])
-def test_fused_denominator_z_pass_is_bit_identical(ctx, shape):
-    """Round 3: the z pass of the denominator convolution rides with the normalisation kernels
-    (normalize_zconv_kernel: same 8-tap fmaf chain, then num / den) instead of writing den and
-    reading it back.  Bit-identical to the separate passes, for the fp32 and the uint16 pipelines,
-    rows that are multiples of four (float4 lanes) and rows that are not (scalar lanes), both stages."""
-    vol16 = synth_volume(shape, seed=sum(shape), as_u16=True)[0]
-    volf = vol16.astype(np.float32) - np.float32(37.0)
-    outs = {}
-    try:
-        for fuse in (1, 0):
-            ctx.set_option("fuse_den_z", fuse)
-            d_in, d_out = ctx.to_device(vol16), ctx.alloc(vol16.nbytes)
-            ctx.denoise_u16(d_in, d_out, shape, SIGMA, 37.0)
-            ctx.sync()
-            u = d_out.download(shape, np.uint16)
-            d_in.free()
-            d_out.free()
-            outs[fuse] = (u, ctx.denoise_f32_host(volf, SIGMA, stages=1),
-                          ctx.denoise_f32_host(volf, SIGMA, stages=2, clip=(0.0, 500.0)))
-    finally:
-        ctx.set_option("fuse_den_z", 1)
-    # stage 1 alone: the kernels run on the same inputs, only the aggregation's arrival order varies
-    # between launches, so compare at the tolerance of two runs of the SAME configuration
-    for a, b in zip(outs[1], outs[0]):
-        d = np.abs(a.astype(np.float64) - b.astype(np.float64))
-        assert d.max() <= (1 if a.dtype == np.uint16 else 0.05), float(d.max())
-        assert np.mean(d > 0) < (2e-3 if a.dtype == np.uint16 else 1.0)
-
-
 def test_wiener_gathers_from_the_interleaved_volume(ctx, oracle):
     """Round 3: the Wiener kernel reads block k's noisy and basic values with one 8-byte load per row
     from an interleaved (noisy, basic) volume (half the cache lines of two gathers) and runs them as
-    the two packed streams of one transform -- per stream the same IEEE operations as before, so the
-    spectra are bit-identical and the stage output differs only by the aggregation's arrival order.
-    Against the separate gathers (option stage_pairvol = 0) on a volume with every group size, and
-    against the oracle on a crop."""
-    shape = (40, 200, 208)
+    the two packed streams of one transform -- per stream the same IEEE operations as the separate
+    gathers (option stage_pairvol = 0): identical outputs, on a volume with every group size, and the
+    CPU port's."""
+    shape = (40, 120, 128)
     noisy = _mixed_volume(shape, 41)
     basic = (noisy + np.random.default_rng(6).normal(0, 2.0, shape)).astype(np.float32)
     keys = _keys_gpu(ctx, basic, SIGMA, 3.0)
@@ -509,15 +388,11 @@ def test_wiener_gathers_from_the_interleaved_volume(ctx, oracle):
             res[pv] = _stage_gpu(ctx, noisy, keys, SIGMA, basic=basic)
     finally:
         ctx.set_option("stage_pairvol", 1)
-    np.testing.assert_allclose(res[1][1], res[0][1], rtol=2e-5)
-    _assert_close_estimates(res[1][0] / res[1][1], res[0][0] / res[0][1], SIGMA)
-    sub = (slice(0, 32), slice(60, 108), slice(40, 88))
-    cn, cb = np.ascontiguousarray(noisy[sub]), np.ascontiguousarray(basic[sub])
-    kc = oracle.blockmatch(cb, SIGMA, 3.0)
-    num_w, den_w = oracle.stage(cn, kc, SIGMA, basic=cb)
-    num_g, den_g = _stage_gpu(ctx, cn, kc, SIGMA, basic=cb)
-    np.testing.assert_allclose(den_g, den_w, rtol=1e-4)
-    _assert_close_estimates(num_g / den_g, num_w / den_w, SIGMA)
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    num_w, den_w = oracle.stage(noisy, keys, SIGMA, basic=basic, port=True)
+    np.testing.assert_array_equal(res[1][0], num_w)
+    np.testing.assert_array_equal(res[1][1], den_w)
 
 
 def test_block_matching_workgroup_orders_give_identical_tables(ctx):
@@ -554,8 +429,7 @@ def test_block_matching_workgroup_orders_give_identical_tables(ctx):
 
 def test_stage_tile_order_option_changes_nothing_but_the_order(ctx):
     """stage_strip = n walks the stage kernels' tile columns in strips of n tile rows (default 3: -0.4 % at
-    1024^3), 0 in raster order.  Same groups, same arithmetic; only the order of the global fp32 adds where
-    neighbouring tiles overlap may differ."""
+    1024^3), 0 in raster order.  Same groups, same arithmetic, integer sums: the same uint16 volume."""
     from aind_exaspim_image_compression.bm4d import denoise_volume
     vol = synth_volume((40, 150, 170), seed=17, as_u16=True)[0]
     ctx.set_option("stage_strip", 0)
@@ -563,7 +437,6 @@ def test_stage_tile_order_option_changes_nothing_but_the_order(ctx):
     try:
         for n in (2, 3, 7):
             ctx.set_option("stage_strip", n)
-            d = np.abs(denoise_volume(vol, SIGMA, 37.0).astype(np.int32) - want.astype(np.int32))
-            assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (n, int(d.max()), float(np.mean(d > 0)))
+            np.testing.assert_array_equal(denoise_volume(vol, SIGMA, 37.0), want, err_msg=f"stage_strip {n}")
     finally:
         ctx.set_option("stage_strip", 3)

@@ -59,12 +59,16 @@ def _worker(rank, world, port, tmp):
     plan = plan_slabs(SHAPE[0], world, rank)
     noisy = torch.from_numpy(np.ascontiguousarray(vol[plan.p0:plan.p1]))
 
+    # the numerator's unit is read off the WHOLE volume: one MAX-reduced int per run
+    from aind_exaspim_image_compression.distributed import global_data_exp
+    E = global_data_exp(noisy[plan.core], dist=dist)
+
     def stage1(x):
-        return torch.from_numpy(O.bm4d(x.numpy(), SIGMA, stages=1))
+        return torch.from_numpy(O.bm4d(x.numpy(), SIGMA, stages=1, data_exp=E))
 
     def stage2(x, basic):
         keys = O.blockmatch(basic.numpy(), SIGMA, O.DEFAULTS["c_match_wie"])
-        num, den = O.stage(x.numpy(), keys, SIGMA, basic=basic.numpy())
+        num, den = O.stage(x.numpy(), keys, SIGMA, basic=basic.numpy(), data_exp=E)
         return torch.from_numpy(O.normalize(num, den))
 
     out = denoise_slab(noisy, plan, SIGMA, stage1, stage2)
@@ -141,5 +145,5 @@ def test_two_rank_slabs_equal_whole_volume(oracle, tmp_path):
     for r in range(world):
         z0, z1 = np.load(tmp_path / f"plan{r}.npy")
         got[z0:z1] = np.load(tmp_path / f"slab{r}.npy")
-    # exact halo (24): identical up to the fp32 summation order of the aggregation
-    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)
+    # exact halo (24) and integer aggregation sums (round 4): the sharded result IS the whole-volume result
+    np.testing.assert_array_equal(got, want)
