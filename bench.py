@@ -524,7 +524,6 @@ ENV_OPTIONS = {                      # A/B switches of tools/dbg: environment va
     "EXABM4D_STAGE_CHUNKS": "stage_chunks",      # z chunks of the stage kernels
     "EXABM4D_STAGE_STRIP": "stage_strip",        # stage kernels: tile columns in strips of n tile rows
     "EXABM4D_STAGE_PAIRVOL": "stage_pairvol",    # Wiener gathers from the interleaved (noisy, basic) volume
-    "EXABM4D_STAGE_QUADS": "stage_quads",        # Wiener stage on teams of 4 (1) or 2 (0) waves
     "EXABM4D_BM_CARRY": "bm_carry",              # block matching: carry between the tiles of a column
     "EXABM4D_BM_XCD_MODE": "bm_xcd_mode",        # block matching: workgroup order
 }
@@ -866,6 +865,10 @@ def main():
             b_in, b_out = ctx.to_device(v256), ctx.alloc(v256.nbytes)
             ctx.denoise_u16(b_in, b_out, v256.shape, SIGMA, OFFSET, params=params, stages=args.stages)
             gpu256 = b_out.download(v256.shape, np.uint16)
+            # a second launch on the same input: the aggregation sums are integers, so the
+            # arrival order of the atomics cannot show -- the same bytes, and the CPU port's
+            ctx.denoise_u16(b_in, b_out, v256.shape, SIGMA, OFFSET, params=params, stages=args.stages)
+            again256 = b_out.download(v256.shape, np.uint16)
             b_in.free()
             b_out.free()
             clean = synth_clean(v256.shape, 1000)
@@ -878,10 +881,11 @@ def main():
                 "gpu_vs_clean": psnr_db(gpu256, clean, peak),
                 "cpu_vs_clean": psnr_db(port256, clean, peak),
                 "delta_db": psnr_db(gpu256, clean, peak) - psnr_db(port256, clean, peak),
-                "gpu_vs_cpu": psnr_db(gpu256, port256, peak),
+                # None = identical volumes (no finite PSNR); rounds 1-3: ~115 dB, up to 4 counts on rare voxels
+                "gpu_vs_cpu": None if not d.any() else psnr_db(gpu256, port256, peak),
+                "gpu_equals_cpu": bool(not d.any()),
+                "second_launch_identical": bool(np.array_equal(gpu256, again256)),
                 "max_abs_u16": int(d.max()), "frac_differing": float(np.mean(d > 0)),
-                # more than the one count of a rounding tie: voxels whose stage-2 group changed because the
-                # last bits of the basic estimate moved a match table (tests/test_pipeline_differences_gpu.py)
                 "frac_beyond_one_count": float(np.mean(d > 1)),
             }
         if args.bm4dnet > 0 and world == 1:

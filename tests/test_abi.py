@@ -32,7 +32,7 @@ def test_struct_sizes_match_the_library():
     assert p.size == ctypes.sizeof(nat.Params)
     assert (p.block, p.step, p.search, p.max_group) == (8, 4, 11, 16)
     assert abs(p.lambda_ht - 2.7) < 1e-6 and abs(p.kaiser_beta - 2.0) < 1e-6
-    assert nat.lib().exabm4d_version() == 302
+    assert nat.lib().exabm4d_version() == 400
 
 
 def test_grid_and_tables_match_the_oracle(oracle):

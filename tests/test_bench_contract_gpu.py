@@ -49,9 +49,10 @@ def test_default_line_has_the_contract_keys():
         assert e["cratio_denoised_same_chunks"] >= e["cratio_zstd5_shuffle"]
     # PSNR vs the CPU port on the same 256^3 volume (BASELINE.json's metric names it): < 0.01 dB apart
     p = d["psnr"]
-    # (a count or two where the estimates are tens of thousands of counts: fp32 sums in another order)
-    assert abs(p["delta_db"]) < 0.01 and p["frac_differing"] < 5e-3
-    assert p["max_abs_u16"] <= 4 and p["frac_beyond_one_count"] < 1e-4
+    # round 4: integer aggregation sums -- the GPU's uint16 volume IS the port's
+    assert p["delta_db"] == 0.0 and p["frac_differing"] == 0.0
+    assert p["max_abs_u16"] == 0 and p["frac_beyond_one_count"] == 0.0
+    assert p["gpu_equals_cpu"] is True and p["second_launch_identical"] is True and p["gpu_vs_cpu"] is None
     assert p["gpu_vs_clean"] > p["noisy_vs_clean"] + 5.0
     assert c["encode"]["exac_v2_port"]["cratio"] > 3.0
 

@@ -79,14 +79,13 @@ def test_carry_with_patches_batches_and_unaligned_planes(ctx, oracle, carry, int
 
 def test_pipeline_with_forced_carry_equals_the_default(ctx, carry):
     """Whole uint16 pipeline with the carry forced on a small volume: the result of the launch without it
-    (same tables; the stage kernels' global fp32 adds are not ordered, so near-ties may round apart)."""
+    (same tables, integer aggregation sums: the same uint16 volume)."""
     from aind_exaspim_image_compression.bm4d import denoise_volume
     vol = synth_volume((96, 48, 56), seed=33, as_u16=True)[0]
     carry(0)
     want = denoise_volume(vol, SIGMA, 37.0)
     carry(2)
-    d = np.abs(denoise_volume(vol, SIGMA, 37.0).astype(np.int32) - want.astype(np.int32))
-    assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (int(d.max()), float(np.mean(d > 0)))
+    np.testing.assert_array_equal(denoise_volume(vol, SIGMA, 37.0), want)
 
 
 def test_large_launch_takes_the_carry_by_default_and_agrees(ctx, carry):
@@ -124,5 +123,4 @@ def test_chunk_local_mode_with_and_without_the_carry(ctx, carry):
     carry(0)
     want = denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8)
     carry(2)
-    d = np.abs(denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8).astype(np.int32) - want.astype(np.int32))
-    assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (int(d.max()), float(np.mean(d > 0)))
+    np.testing.assert_array_equal(denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8), want)

@@ -59,13 +59,12 @@ def test_compare_with_bm4d_equals_the_per_patch_loop():
             y = model(x)[0, 0].cpu().numpy()
         denoised = tf_o.inverse(y)[5:-5, 5:-5, 5:-5]
         np.testing.assert_array_equal(got["denoised"][i], denoised)
-        # ground truth: fp32 aggregation order differs from the oracle's (and from run to run),
-        # truncation to int may flip a count where the estimate sits on an integer
+        # ground truth: one batched BM4D call for all patches == one call per patch == the oracle
         gt_dev = got["denoised_gt"][i]
         assert gt_dev.dtype == np.int64
         alone = np.maximum(B.bm4d(noise, 10), 0).astype(int)
-        assert np.abs(gt_dev - alone).max() <= 1 and np.mean(gt_dev != alone) < 1e-3
-        assert np.abs(gt_dev - want_gt).max() <= 1 and np.mean(gt_dev != want_gt) < 1e-3
+        np.testing.assert_array_equal(gt_dev, alone)
+        np.testing.assert_array_equal(gt_dev, want_gt)
         assert got["cratio"][i] == ref_cratio(denoised, Zlib())
         assert got["cratio_noise"][i] == ref_cratio(noise, Zlib())
         assert got["cratio_gt"][i] == ref_cratio(gt_dev, Zlib())

@@ -17,16 +17,17 @@ def test_bm4d_shim_call_signature(oracle):
     raw, _ = synth_volume((64, 64, 64), seed=31)
     teacher = np.clip(bm4d(raw, SIGMA), 0, 65535.0)
     want = np.clip(oracle.bm4d(raw, SIGMA), 0, 65535.0)
-    assert teacher.dtype == np.float32 and psnr(teacher, want, 1000.0) > 80.0
+    assert teacher.dtype == np.float32
+    np.testing.assert_array_equal(teacher, want)
     crop = raw[5:-5, 5:-5, 5:-5]
     gt = np.maximum(bm4d(crop, 10), 0).astype(int)
     want = np.maximum(oracle.bm4d(np.ascontiguousarray(crop), 10.0), 0).astype(int)
-    assert np.mean(gt != want) < 1e-3 and np.abs(gt - want).max() <= 1
+    np.testing.assert_array_equal(gt, want)
     from aind_exaspim_image_compression.bm4d import denoise_patches
     batch = np.stack([raw, raw[::-1].copy()])
     t2 = denoise_patches(batch, SIGMA)
     assert t2.shape == batch.shape and t2.min() >= 0.0
-    assert psnr(t2[0], teacher, 1000.0) > 80.0
+    np.testing.assert_array_equal(t2[0], teacher)          # a patch of a batch == the patch alone
     # sub-batching (one device call per patch here) gives the same teachers
     import aind_exaspim_image_compression.bm4d as B
     old = B._MAX_VOXELS_PER_CALL
@@ -35,7 +36,7 @@ def test_bm4d_shim_call_signature(oracle):
         t3 = denoise_patches(batch, SIGMA)
     finally:
         B._MAX_VOXELS_PER_CALL = old
-    assert psnr(t3, t2, 1000.0) > 80.0
+    np.testing.assert_array_equal(t3, t2)
 
 
 def test_slab_driver_single_gpu(oracle):
@@ -45,15 +46,14 @@ def test_slab_driver_single_gpu(oracle):
     plan = plan_slabs(48, 1, 0)
     den = SlabDenoiser(vol.shape, SIGMA, "cuda:0")
     out = denoise_slab(torch.from_numpy(vol).cuda(), plan, SIGMA, den.stage1, den.stage2)
-    want = oracle.bm4d(vol, SIGMA)
-    assert psnr(out.cpu().numpy(), want, 1000.0) > 80.0
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.bm4d(vol, SIGMA))
 
 
 def test_two_stage_parity_on_a_multi_tile_volume(ctx, oracle):
     """112 x 100 x 108 uint16, both stages: dozens of tiles, several z-layers per workgroup chunk,
     ragged extents on two axes (clamped last grid points) -- the whole device pipeline (block
     matching, half-group stage kernels, denominator convolution, uint16 rounding) against the
-    oracle: at most one count off on a handful of voxels, same PSNR to 1e-3 dB."""
+    oracle: the same uint16 volume."""
     shape = (112, 100, 108)
     vol, clean = synth_volume(shape, seed=77, as_u16=True)
     want = oracle.bm4d_u16(vol, 24.0, 37.0, stages=2)
@@ -66,10 +66,7 @@ def test_two_stage_parity_on_a_multi_tile_volume(ctx, oracle):
     finally:
         d_in.free()
         d_out.free()
-    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    assert d.max() <= 2 and np.mean(d > 0) < 1e-3 and np.mean(d > 1) < 1e-5
-    peak = float(clean.max() - clean.min())
-    assert abs(psnr(got, clean + 37, peak) - psnr(want, clean + 37, peak)) < 1e-3
+    np.testing.assert_array_equal(got, want)
 
 
 @pytest.fixture(scope="module")
@@ -98,9 +95,9 @@ def test_full_size_1024_properties(full1024):
     crop = np.ascontiguousarray(vol[o[0]:o[0] + 256, o[1]:o[1] + 256, o[2]:o[2] + 256])
     from aind_exaspim_image_compression.bm4d import denoise_volume
     sub = denoise_volume(crop, SIGMA, offset=bench.OFFSET)
-    a = sub[48:-48, 48:-48, 48:-48].astype(np.int32)
-    b = full[o[0] + 48:o[0] + 208, o[1] + 48:o[1] + 208, o[2] + 48:o[2] + 208].astype(np.int32)
-    assert np.abs(a - b).max() <= 1 and np.mean(a != b) < 1e-3
+    # integer aggregation sums and a fixed unit: the same blocks add the same integers in crop and volume
+    np.testing.assert_array_equal(sub[48:-48, 48:-48, 48:-48],
+                                  full[o[0] + 48:o[0] + 208, o[1] + 48:o[1] + 208, o[2] + 48:o[2] + 208])
     resid = full[::8, ::8, ::8].astype(np.float32) - vol[::8, ::8, ::8].astype(np.float32)
     assert 0.8 * SIGMA < resid.std() < 1.05 * SIGMA
     assert abs(resid.mean()) < 0.5
@@ -114,17 +111,13 @@ def _oracle_crop_check(oracle, vol, got, origin, edge, radius, stages):
     crop = np.ascontiguousarray(vol[o[0]:o[0] + e, o[1]:o[1] + e, o[2]:o[2] + e])
     want = oracle.bm4d_u16(crop, SIGMA, 37.0, stages=stages)[r:e - r, r:e - r, r:e - r]
     have = got[o[0] + r:o[0] + e - r, o[1] + r:o[1] + e - r, o[2] + r:o[2] + e - r]
-    d = np.abs(have.astype(np.int32) - want.astype(np.int32))
-    assert d.max() <= 1 and np.mean(d > 0) < 2e-3, (origin, int(d.max()), float(np.mean(d > 0)))
-    ref = crop[r:e - r, r:e - r, r:e - r].astype(np.float64)       # PSNR against the noisy input:
-    peak = 65535.0                                                   # same reference for both
-    assert abs(psnr(have, ref, peak) - psnr(want, ref, peak)) < 0.01
+    np.testing.assert_array_equal(have, want, err_msg=f"crop at {origin}")
 
 
 def test_config3_1024_against_the_oracle_on_interior_crops(full1024, oracle):
     """BASELINE.json configs[2] (1024^3, two stages) anchored on the ORACLE: two 144^3 crops at
-    different depths, interiors of 48^3 voxels (dependency radius 48 for two stages): uint16
-    within one count, PSNR difference < 0.01 dB."""
+    different depths, interiors of 48^3 voxels (dependency radius 48 for two stages): the oracle's
+    uint16 values, voxel for voxel."""
     vol, full = full1024
     for origin in ((400, 516, 128), (40, 860, 700)):
         _oracle_crop_check(oracle, vol, full, origin, 144, 48, 2)

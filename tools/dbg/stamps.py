@@ -5,7 +5,6 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "aind-exaspim-image-co
 from aind_exaspim_image_compression import _native as nat
 import bench
 ctx = nat.context(0)
-ctx.set_option("stage_pairs", int(os.environ.get("PAIRS", "1")))
 shape = (int(os.environ.get("SIZE", "512")),)*3
 vol = bench.synth_u16(shape, 1000)
 d_in = ctx.to_device(vol); d_out = ctx.alloc(vol.nbytes)

@@ -6,7 +6,10 @@ under `timeout`):
 Every iteration draws a shape (8..72 per axis, ragged and even / odd row lengths), a data regime
 (structure + noise, white noise, extremes 0 / 65535, constant, sparse), sigma and offset, and checks
   * stage-1 match tables of the uint16 entry point: bit-exact against the oracle,
-  * the two-stage uint16 pipeline: within one count of the oracle on (almost) every voxel,
+  * the two-stage uint16 pipeline: the oracle's uint16 volume, voxel for voxel (round 4: the aggregation
+    sums are integers; rounds 1-3 allowed a count, and an "account" of changed stage-2 groups beyond it),
+    also with the stage kernels' launch shape drawn at random (z chunks, tile order, gather form) and on
+    a second launch,
   * the chunk coder on a random chunk grid: bytes identical to the C restatement, exact decode.
 Prints one line per iteration and a summary; exit code 1 on the first mismatch."""
 import os
@@ -54,44 +57,6 @@ def draw_volume(rng, shape):
     return name, v
 
 
-def unexplained_voxels(ctx, vol, sigma, offset, got, ref):
-    """The account tests/test_pipeline_differences_gpu.py gives of a difference, applied to one volume: the
-    GPU's stage-2 match tables on ITS basic estimate against the oracle's on the oracle's; a voxel where the
-    two uint16 results differ must lie inside the aggregation footprint of a reference block whose group
-    changed, or on a rounding near-tie of the oracle's estimate.  Returns (voxels without such an account,
-    share of groups that changed)."""
-    shape, n = vol.shape, vol.size
-    f = vol.astype(np.float32) - np.float32(offset)
-    basic_o = O.bm4d(f, sigma, stages=1).astype(np.float32)
-    pre_o = O.bm4d(f, sigma, stages=2).astype(np.float32) + np.float32(offset)
-    d_in, d_out = ctx.to_device(f), ctx.alloc(4 * n)
-    ctx.denoise_f32(d_in, d_out, shape, sigma, stages=1)
-    ctx.sync()
-    basic_g = d_out.download(shape, np.float32)
-    g = [len(_native.grid_positions(m)) for m in shape]
-    d_keys = ctx.alloc(g[0] * g[1] * g[2] * 64)
-    keys = {}
-    for name, basic in (("gpu", basic_g), ("oracle", basic_o)):
-        d_in.upload(basic)
-        ctx.blockmatch(d_in, shape, sigma, _native.default_params().c_match_wie, d_keys)
-        ctx.sync()
-        keys[name] = d_keys.download((g[0], g[1], g[2], 16), np.uint32)
-    for b in (d_in, d_out, d_keys):
-        b.free()
-    # same basic estimate -> the GPU's stage-2 tables are the oracle's, bit for bit
-    if not np.array_equal(keys["oracle"], O.blockmatch(basic_o, sigma, _native.default_params().c_match_wie)):
-        return -1, 0.0
-    changed = np.any((keys["gpu"] & 0x7FF) != (keys["oracle"] & 0x7FF), axis=-1)
-    foot = np.zeros(shape, bool)
-    pz, py, px = (_native.grid_positions(m) for m in shape)
-    for iz, iy, ix in zip(*np.nonzero(changed)):
-        z, y, x = int(pz[iz]), int(py[iy]), int(px[ix])
-        foot[max(0, z - 5):z + 13, max(0, y - 5):y + 13, max(0, x - 5):x + 13] = True
-    tie = np.abs(pre_o - np.floor(pre_o) - np.float32(0.5)) <= 2e-5 * 65535.0
-    diff = got.astype(np.int64) != ref.astype(np.int64)
-    return int((diff & ~foot & ~tie).sum()), float(changed.mean())
-
-
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -106,11 +71,15 @@ def main():
             shape = shape[:2] + (shape[2] // 2 * 2,)
         name, vol = draw_volume(rng, shape)
         sigma = float(rng.choice([8.0, 16.0, 24.0, 60.0, 110.0]))
-        offset = float(rng.choice([0.0, 37.0, 100.5]))
+        offset = float(rng.choice([0.0, 37.0, 100.5, 36.73]))
         f = vol.astype(np.float32) - np.float32(offset)
         # block matching's launch variants: carry between tiles forced / off, workgroup order (tables must not care)
         ctx.set_option("bm_carry", int(rng.choice([0, 2, 2])))
         ctx.set_option("bm_xcd_mode", int(rng.integers(0, 4)))
+        # ... and the stage kernels' (sums must not care)
+        ctx.set_option("stage_chunks", int(rng.choice([0, 0, 1, 3])))
+        ctx.set_option("stage_strip", int(rng.choice([0, 2, 3])))
+        ctx.set_option("stage_pairvol", int(rng.integers(0, 2)))
 
         # stage-1 tables (uint16 entry point: integer kernel where it applies)
         g = [len(_native.grid_positions(n)) for n in shape]
@@ -128,20 +97,9 @@ def main():
         got = d_out.download(shape, np.uint16)
         ref = O.bm4d_u16(vol, sigma, offset)
         d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
-        # one count where the two fp32 summation orders round apart, or where the last bits of the
-        # basic estimate moved a stage-2 match table (tests/test_pipeline_differences_gpu.py pins
-        # both mechanisms; volumes with isolated 0 / 65535 voxels reach 0.5 % by the second one,
-        # whatever the offset -- tools/dbg/tie_probe.py).  A changed group can move a voxel by more
-        # than a count (seen: 2 at sigma 110 on an "extremes" volume, 3 in bench.py's psnr block);
-        # the aggregation order varies between launches, so the same input does not always show it
-        ok_pipe = d.max() <= 3 and np.mean(d > 1) < 1e-4 and np.mean(d > 0) < 2e-2
+        ctx.denoise_u16(d_vol, d_out, shape, sigma, offset)                 # again: a function of its input
+        ok_pipe = not d.any() and np.array_equal(d_out.download(shape, np.uint16), got)
         note = ""
-        if not ok_pipe and np.mean(d > 0) < 2e-2:
-            # beyond the usual bound (seen: 4 counts next to a 60000-count box in noise): acceptable only
-            # if every differing voxel is accounted for by a changed stage-2 group or a rounding near-tie
-            left, share = unexplained_voxels(ctx, vol, sigma, offset, got, ref)
-            ok_pipe = left == 0
-            note = f" [groups changed {share:.2%}, voxels without an account {left}]"
         del f
 
         # chunk coder on the denoised volume, random chunk grid

@@ -1,7 +1,10 @@
-"""Stress the two-waves-per-group stage kernels on volumes with every group-size regime at
-multi-layer scale, against the one-wave-per-group kernels (same library, option "stage_pairs").
+"""Stress the stage kernels on volumes with every group-size regime at multi-layer scale: the CPU
+port's uint16 volume (bit-identical to the oracle's, tests/test_oracle_bm4d.py), voxel for voxel, from two
+launch shapes (automatic z chunks; one chunk per tile column).  Round 4: exact equality (integer
+aggregation sums); rounds 2-3 compared with the one-wave-per-group kernels within a count.
 
-usage: python tools/stress_stage.py [edge=384]   (wrap in `timeout`: a hang is the failure mode)"""
+usage: python tools/stress_stage.py [edge=192]   (wrap in `timeout`: a hang is the failure mode; the CPU
+port needs about a second per 10^7 voxels and stage on 16 threads)"""
 import os
 import sys
 import time
@@ -37,44 +40,35 @@ def volumes(edge):
 
 
 def main():
-    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+    from oracle import bm4d_oracle as O
+    edge = int(sys.argv[1]) if len(sys.argv) > 1 else 192
     ctx = _native.context(0)
     for name, vol in volumes(edge):
         line = f"{name:38s} {str(vol.shape):16s}"
         for stages in (1, 2):
-            outs = []
-            for pairs in (1, 0):
-                ctx.set_option("stage_pairs", pairs)
+            want = O.bm4d_u16(vol, bench.SIGMA, bench.OFFSET, stages=stages, port=True)
+            for chunks in (0, 1):
+                ctx.set_option("stage_chunks", chunks)
                 d_in = ctx.to_device(vol)
                 d_out = ctx.alloc(vol.nbytes)
                 t0 = time.perf_counter()
                 ctx.denoise_u16(d_in, d_out, vol.shape, bench.SIGMA, bench.OFFSET, stages=stages)
                 ctx.sync()
                 dt = time.perf_counter() - t0
-                outs.append((d_out.download(vol.shape, np.uint16), dt))
+                got = d_out.download(vol.shape, np.uint16)
                 d_in.free()
                 d_out.free()
-            diff = np.abs(outs[0][0].astype(np.int32) - outs[1][0].astype(np.int32))
-            if stages == 1:
-                # one stage, same match tables: only the aggregation order differs
-                ok = diff.max() <= 1 and np.mean(diff > 0) < 5e-3
-            else:
-                # stage-2 matching runs on the stage-1 estimate, whose last bits depend on the order
-                # of the aggregation atomics: isolated voxels may move by several counts between any
-                # two runs (a different block enters a group)
-                ok = np.mean(diff > 0) < 5e-3 and np.mean(diff > 1) < 1e-6
-            line += (f"  | {stages} stage{'s' if stages > 1 else ' '}: pairs {outs[0][1]*1e3:6.1f} ms single "
-                     f"{outs[1][1]*1e3:6.1f} ms max|d| {diff.max()} frac {np.mean(diff > 0):.1e} "
-                     f"{'OK' if ok else 'MISMATCH'}")
-            if not ok:
-                print(line, flush=True)
-                bad = np.argwhere(diff > 1)
-                print("   first mismatches (z, y, x):", bad[:6].tolist(), "z range", bad[:, 0].min(), bad[:, 0].max(),
-                      "count", len(bad), flush=True)
-                if os.environ.get("STRESS_KEEP_GOING") != "1":
-                    sys.exit(1)
+                ok = np.array_equal(got, want)
+                line += f"  | {stages} stage{'s' if stages > 1 else ' '} chunks {chunks}: {dt*1e3:6.1f} ms {'OK' if ok else 'MISMATCH'}"
+                if not ok:
+                    print(line, flush=True)
+                    bad = np.argwhere(got != want)
+                    print("   first mismatches (z, y, x):", bad[:6].tolist(), "z range", bad[:, 0].min(), bad[:, 0].max(),
+                          "count", len(bad), flush=True)
+                    if os.environ.get("STRESS_KEEP_GOING") != "1":
+                        sys.exit(1)
         print(line, flush=True)
-    ctx.set_option("stage_pairs", 1)
+    ctx.set_option("stage_chunks", 0)
     print("all volumes agree")
 
 
