@@ -16,6 +16,10 @@ constexpr int TBUF = 640;                 // per-wave transpose buffer: [8][8][8
 constexpr int TSI = 80, TSJ = 10;         // (found by enumeration) make the b64 writes and b128 reads
                                           // of all four transposes bank-conflict-free but one 2-way write
 
+#ifndef EXABM4D_TR_PROBE
+#define EXABM4D_TR_PROBE 0                // 1: TIMING PROBE, wrong results -- the [hi][r][lo] writes land 8 elements lower
+#endif                                    // for odd hi: conflict-free under ds_write_b64's mod-32 banking
+#define TRA_PROBE(hi) (EXABM4D_TR_PROBE ? 8 * ((hi) & 1) : 0)
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 // (In C++ `(f2)(a, b)` is a cast of a comma expression, not a vector literal.)
@@ -268,7 +272,7 @@ __device__ __forceinline__ void pair_fwd(const TableT& T, f2* tb, int hi, int lo
     transpose_lo(v, lo);                                         // L2: hi = z, lo = y, regs x
 #else
 #pragma unroll
-    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = v[y];  // buffer [z][y][x]
+    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo - TRA_PROBE(hi)] = v[y];  // buffer [z][y][x]
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, v);                         // L2: hi = z, lo = y, regs x
     cbar();
@@ -304,13 +308,13 @@ __device__ __forceinline__ void pair_fwd_x2(const TableT& T, f2* tb, int hi, int
     }
     dct8_fwd2(T, a);                                             // A along y
 #pragma unroll
-    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = a[y];
+    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo - TRA_PROBE(hi)] = a[y];
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, a);                         // A -> L2 (in flight)
     cbar();
     dct8_fwd2(T, b);                                             // B along y
 #pragma unroll
-    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo] = b[y];
+    for (int y = 0; y < 8; y++) tb[hi * TSI + y * TSJ + lo - TRA_PROBE(hi)] = b[y];
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, b);                         // B -> L2 (in flight)
     cbar();
@@ -359,13 +363,13 @@ __device__ __forceinline__ void pair_inv_x2(const TableT& T, f2* tb, int hi, int
     cbar();
     dct8_inv2(T, a);                                             // A along x
 #pragma unroll
-    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = a[x];
+    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo - TRA_PROBE(hi)] = a[x];
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, a);
     cbar();
     dct8_inv2(T, b);                                             // B along x
 #pragma unroll
-    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = b[x];
+    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo - TRA_PROBE(hi)] = b[x];
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, b);
     cbar();
@@ -395,7 +399,7 @@ __device__ __forceinline__ void pair_inv(const TableT& T, f2* tb, int hi, int lo
     transpose_lo(v, lo);                                         // L1: hi = z, lo = x, regs y
 #else
 #pragma unroll
-    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo] = v[x];  // buffer [z][x][y]
+    for (int x = 0; x < 8; x++) tb[hi * TSI + x * TSJ + lo - TRA_PROBE(hi)] = v[x];  // buffer [z][x][y]
     cbar();
     load8p(tb + hi * TSI + lo * TSJ, v);                         // L1: hi = z, lo = x, regs y
     cbar();

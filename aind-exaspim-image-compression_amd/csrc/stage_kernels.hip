@@ -223,10 +223,22 @@ __device__ __forceinline__ long long magic_bits(double m) {
 // R(d) of DESIGN.md 3.7 for two values at once: integer-subtraction seed, three Newton steps as fused
 // multiply-adds (v_pk_fma_f32) -- IEEE operations only, so the oracle produces the same bits (v_rcp_f32
 // is a table the CPU does not have), and about what two quarter-rate v_rcp_f32 cost.
+#ifndef EXABM4D_WIE_ILV
+#define EXABM4D_WIE_ILV 2                      // Newton chains interleaved per scheduling region (0: no limit)
+#endif
+#ifndef EXABM4D_NR_ITERS
+#define EXABM4D_NR_ITERS 3                     // (A/B builds only: the specification says three)
+#endif
+#ifndef EXABM4D_WIE_RCP
+#define EXABM4D_WIE_RCP 0                      // 1 (timing probe, wrong bits): v_rcp_f32 as in rounds 1-3
+#endif
 __device__ __forceinline__ f2 rcp_nr2(f2 d) {
+#if EXABM4D_WIE_RCP
+    return mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+#endif
     f2 r = mk2(__uint_as_float(0x7EF311C7u - __float_as_uint(d.x)), __uint_as_float(0x7EF311C7u - __float_as_uint(d.y)));
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < EXABM4D_NR_ITERS; i++) {
         const f2 t = __builtin_elementwise_fma(-d, r, (f2)(1.0f));
         r = __builtin_elementwise_fma(t, r, r);
     }
@@ -415,9 +427,9 @@ __device__ __forceinline__ void wiener_half_local(f16v (&S)[4], const f16v (&SB)
             const f2 f = W * x[k];
             A[2 * k] = f.x;
             A[2 * k + 1] = f.y;
-            // one coefficient pair at a time: interleaving the Newton chains of several k for latency
-            // costs the registers the two spectra leave (30 spilled without this)
-            __builtin_amdgcn_sched_barrier(0);
+            // EXABM4D_WIE_ILV coefficient pairs at a time: interleaving the Newton chains of ALL k for latency
+            // costs the registers the two spectra leave (30 spilled), one at a time exposes the chain
+            if (EXABM4D_WIE_ILV && (k % EXABM4D_WIE_ILV) == 0) __builtin_amdgcn_sched_barrier(0);
         }
         S[jp] = A;
     }
