@@ -111,7 +111,7 @@ SIGNATURES = {
     "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_chunked_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _I, _I, _F, _F, _PP,
                                              _I]),
-    "exabm4d_blockmatch_plan": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]),
+    "exabm4d_blockmatch_plan": (_I, [_CTX, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]),
     "exabm4d_denoise_chunked_u16_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
@@ -630,14 +630,26 @@ def check_host_volume_pair(src, dst):
         raise ValueError("source and destination may not overlap")
 
 
-def blockmatch_plan(shape, batch=1):
+def slab_order_tile(position, columns, q):
+    """Tile of launch position ``position`` (a workgroup's ticket, bm_kernels.hip ORDER) in slab order:
+    XCD c = position mod 8 walks positions [c q, (c + 1) q) of every slab of ``columns`` tiles; returns
+    (slab, column) or None for a padding position.  The host-side mirror of ``xcd_slab_sync``: the tile one
+    slab below has position - 8 q, i.e. a smaller ticket."""
+    c, j = position & 7, position >> 3
+    slab, w = divmod(j, q)
+    t = c * q + w
+    return (slab, t) if t < columns else None
+
+
+def blockmatch_plan(shape, batch=1, ctx=None):
     """The launch block matching chooses for this geometry (host logic of libexabm4d.so, no GPU needed):
     dict with the tile grid, the slab-order parameter, whether tiles carry their top cell layer upwards
-     and the device memory that takes."""
+     and the part of the context's scratch that takes.  ``ctx``: follow that context's
+    options (None: the defaults)."""
     out = (ctypes.c_int32 * 6)()
     nbytes = ctypes.c_uint64()
-    rc = lib().exabm4d_blockmatch_plan(int(shape[0]), int(shape[1]), int(shape[2]), int(batch), out,
-                                       ctypes.byref(nbytes))
+    rc = lib().exabm4d_blockmatch_plan(ctx.handle if ctx is not None else None, int(shape[0]), int(shape[1]),
+                                       int(shape[2]), int(batch), out, ctypes.byref(nbytes))
     if rc != 0:
         raise ValueError("blockmatch_plan: %s" % lib().exabm4d_last_error(None).decode())
     return {"tiles_z": out[0], "tiles_y": out[1], "tiles_x": out[2], "slab_order_q": out[3], "carry": bool(out[4]),

@@ -54,11 +54,18 @@ struct TileShape {
 // a tile advances by EIGHT layers: wave w computes cell layer L = 8 tz + w and owns the reference layer
 // L - 1 -- its lower cells are wave w - 1's sums (LDS), and for wave 0 they are the sums wave 7 of the
 // tile BELOW formed, which travel through global memory: [2][columns][22 (dz, pass)][2 rounds][33 x 64],
-// a slot per column and tile parity.  Tiles run one per workgroup in slab order (xcd_slab_sync: all of
-// slab tz - 1 is dispatched before any of slab tz), so the producer of a tile's carry started a whole
-// slab earlier; `done[column]` (tiles finished) makes that a guarantee instead of a likelihood: waves 0
-// and 7 wait for done >= tz before they read / overwrite a slot, and a workgroup never waits for a
-// later one, so the wait cannot deadlock (per XCD too: a slab position belongs to the same XCD in every slab).  All carry traffic is system-scope (stores written through,
+// a slot per column and tile parity.  `done[column]` (tiles finished) orders producer and consumer: waves 0
+// and 7 wait for done >= tz before they read / overwrite a slot.
+// ORDER (round 4): a workgroup does not take its tile from blockIdx -- HIP does not promise that workgroups
+// start in id order -- but from a TICKET: thread 0 draws `atomicAdd(ticket, 1)` when the workgroup starts,
+// and the ticket goes through the slab-order map (xcd_slab_sync).  The producer of a tile's carry is the
+// same slab position one slab earlier: ticket - 8 q.  A smaller ticket has been drawn earlier, so its
+// workgroup is resident or finished, and it in turn only waits for a smaller ticket still: by induction
+// every wait ends, whatever order the hardware dispatches in (the look-back argument of rocPRIM's scans).
+// The poll is bounded all the same (CARRY_POLL_LIMIT, seconds): on expiry the wave raises bit 0 of the
+// context's status word (host-visible), goes on WITHOUT a valid carried layer -- that launch's tables are
+// void -- and the host reports EXABM4D_ERR_HIP at its next synchronisation and switches the carry off for
+// the context (exabm4d_api.hip: check_async_status); never a hang.  All carry traffic is system-scope (stores written through,
 // loads and the LDS-DMA prefetch with sc0 sc1): no assumption about which XCD's L2 a tile runs on.  Wave 0
 // fetches a (dz, pass)'s two rounds by LDS-DMA one plane ahead of their use: no registers, no wait in
 // front of the exchange barriers.  The same sums enter the same adds: tables are unchanged.
@@ -69,7 +76,11 @@ struct Carry {
     int strip;               // tile order inside a slab: strips of this many tile rows, column-major (0 = raster)
     uint32_t* buf;           // [2][columns][CARRY_TILE]
     int* done;               // [columns]: tiles of the column that have finished (zeroed per launch)
+    int* ticket;             // the launch's ticket counter (zeroed per launch), see ORDER above
+    unsigned* status;        // host-visible status word of the context: bit 0 = a carry wait ran out
+    int fault;               // debug option "bm_carry_fault": every wait counts as run out (tests of the error path)
 };
+constexpr int CARRY_POLL_LIMIT = 1 << 23;       // x s_sleep(32) = 2048 cycles: ~7 s at 2.4 GHz
 // Both rounds of one (dz, pass) into `dst` (2 * CARRY_ROUND elements, linear): 16 full 1 KB transfers
 // and one of 512 bytes.
 template <class T>
@@ -83,10 +94,27 @@ __device__ __forceinline__ void carry_prefetch(const T* src, T* dst, int lane) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4096 + 4 * lane),
                                          (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 17);
 }
-__device__ __forceinline__ void carry_wait_for(const int* done, int tiles, int lane) {
-    if (lane == 0)
-        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < tiles)
+__device__ __forceinline__ void carry_wait_for(const int* done, int tiles, int lane, const Carry& carry) {
+    if (lane == 0) {
+        int polls = carry.fault ? CARRY_POLL_LIMIT : 0;
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < tiles) {
+            if (++polls > CARRY_POLL_LIMIT) {
+                __hip_atomic_fetch_or(carry.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
             __builtin_amdgcn_s_sleep(32);
+        }
+        // (the forced fault must not depend on a race with the producer)
+        if (carry.fault) __hip_atomic_fetch_or(carry.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// The workgroup's position in the launch order: its ticket when tiles carry (see ORDER), else its id.
+__device__ __forceinline__ int launch_position(const Carry& carry) {
+    if (!carry.on) return (int)blockIdx.x;
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(carry.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_ticket;
 }
 
 // Each WAVE (= one z-layer of 8x8 cells) streams the candidate planes it needs through its own
@@ -115,7 +143,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const int per = tiles_y * tiles_x, cols = per * nbatch;
     int tz, col;
     if (xcd_q) {
-        const int t = xcd_slab_sync(blockIdx.x, cols, xcd_q);
+        const int t = xcd_slab_sync(launch_position(carry), cols, xcd_q);
         if (t < 0) return;                         // padding of the slab order
         tz = t / cols;
         col = t - tz * cols;
@@ -181,7 +209,7 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const bool lower_carried = carry.on && cz == 0 && tz > 0;          // the lower layer is the tile below's top layer
     const bool carries = carry.on && cz == TCZ - 1 && L + 1 <= g.az;   // ... and this wave's sums are the next tile's
     const bool ref_ok = ref_yx && active && (cz > 0 || lower_carried);
-    if ((lower_carried || carries) && tz > 0) carry_wait_for(done_col, tz, lane);
+    if ((lower_carried || carries) && tz > 0) carry_wait_for(done_col, tz, lane, carry);
     const int rz = STEP * iz;
 
     uint32_t list[MAXG];
@@ -485,7 +513,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     const int per = tiles_y * tiles_x, cols = per * nbatch;
     int tz, col;
     if (xcd_q) {
-        const int t = xcd_slab_sync(blockIdx.x, cols, xcd_q);
+        const int t = xcd_slab_sync(launch_position(carry), cols, xcd_q);
         if (t < 0) return;                         // padding of the slab order
         tz = t / cols;
         col = t - tz * cols;
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     const bool lower_carried = carry.on && cz == 0 && tz > 0;          // the lower layer is the tile below's top layer
     const bool carries = carry.on && cz == TCZ - 1 && L + 1 <= g.az;   // ... and this wave's sums are the next tile's
     const bool ref_ok = ref_yx && active && (cz > 0 || lower_carried);
-    if ((lower_carried || carries) && tz > 0) carry_wait_for(done_col, tz, lane);
+    if ((lower_carried || carries) && tz > 0) carry_wait_for(done_col, tz, lane, carry);
     const int rz = STEP * iz;
 
     uint32_t list[MAXG];
@@ -850,30 +878,9 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
 // instead of one long row of tiles, a smaller set of cache lines (measured at 1024^3 on a noisy volume: fp32
 // kernel 109.4 -> 107.5 ms with strips of 2, 108.7 with 3, 110.0 with 4; the integer kernel and the fp32 kernel
 // on the pipeline's smooth basic estimate are indifferent -- DESIGN.md 5.1d).
-int g_bm_xcd_mode = 2;
-// Carry between the tiles of a column (CARRY above): 0 = off (tiles advance by seven cell layers), 1 = on
-// wherever it saves a tile per column, 2 = on whenever a column has two tiles (tests).
-int g_bm_carry = 1;
+// (BmOpts::xcd_mode, default 2; BmOpts::carry: 0 = off (tiles advance by seven cell layers), 1 = on wherever it
+// saves a tile per column, 2 = on whenever a column has two tiles (tests).  Per context since round 4.)
 
-struct TilePlan {
-    int ty, tx, tz, xq, carry;
-};
-static TilePlan plan_tiles(const VolGeom& g, int batch, int try_, int trx, bool have_carry) {
-    TilePlan p;
-    p.ty = (g.ay + try_ - 1) / try_;
-    p.tx = (g.ax + trx - 1) / trx;
-    const long long cols = (long long)p.ty * p.tx * batch;          // columns of tiles: (batch element, ty, tx)
-    const int tz7 = (g.az + TCZ - 2) / (TCZ - 1), tz8 = g.az / TCZ + 1;
-    const bool slab = g_bm_xcd_mode != 0 && cols >= 512;
-    // The carry pays where it saves a tile per column (a 64^3 patch: 15 reference layers = 3 tiles without,
-    // 2 with) AND a slab is a couple of rounds of the 256 CUs: a tile waits for the tile below it, and when
-    // both are resident together the upper one only spins on a CU (a single small volume gains nothing).
-    const bool worth = tz8 >= 2 && tz8 < tz7 && slab;
-    p.carry = (have_carry && g_bm_carry != 0 && (worth || (g_bm_carry == 2 && tz8 >= 2))) ? 1 : 0;
-    p.tz = p.carry ? tz8 : tz7;
-    p.xq = (p.carry || (slab && p.tz >= 2)) ? (int)((cols + 7) / 8) : 0;
-    return p;
-}
 // Tile shape: fewer (y, x) tiles = fewer idle cell lanes (64^3 patches: 5 flat tiles against 9 cubes)
 template <class Cube, class Flat>
 static bool flat_tiles(const VolGeom& g) {
@@ -882,36 +889,43 @@ static bool flat_tiles(const VolGeom& g) {
     };
     return tiles(Flat::TRY, Flat::TRX) < tiles(Cube::TRY, Cube::TRX);
 }
-size_t bm_carry_bytes(const VolGeom& g, int batch) {
-    if (g.az <= 0 || g.ay <= 0 || g.ax <= 0) return 0;
-    // the same decision the launcher takes (the float and the integer kernel share tile shapes)
+// The launch block matching chooses for a geometry (host logic only; the float and the integer kernel share
+// tile shapes).  Evaluated ONCE per launch by the API layer, which also provides plan.carry_bytes of device
+// memory when plan.carry is set.
+BmPlan bm_plan(const VolGeom& g, int batch, const BmOpts& opt) {
     using Cube = TileShape<8, 8>;
     using Flat = TileShape<4, 16>;
-    const bool flat = flat_tiles<Cube, Flat>(g);
-    const TilePlan p = plan_tiles(g, batch, flat ? Flat::TRY : Cube::TRY, flat ? Flat::TRX : Cube::TRX, true);
-    if (!p.carry) return 0;
-    const size_t cols = (size_t)p.ty * p.tx * (size_t)batch;
-    const size_t need = 2 * cols * CARRY_TILE * sizeof(uint32_t) + cols * sizeof(int);
-    return need <= ((size_t)16 << 30) ? need : 0;        // 744 KB per column: beyond 16 GB the launch goes without
-}
-
-// The launch block matching would choose for this geometry: {tile slabs, tile rows, tile columns, slab-order
-// parameter (0 = contiguous per XCD), carry on, flat tile shape} -- host logic only, for the CPU tests.
-void bm_plan(const VolGeom& g, int batch, int out[6]) {
-    using Cube = TileShape<8, 8>;
-    using Flat = TileShape<4, 16>;
-    const bool flat = flat_tiles<Cube, Flat>(g);
-    const TilePlan p = plan_tiles(g, batch, flat ? Flat::TRY : Cube::TRY, flat ? Flat::TRX : Cube::TRX,
-                                  bm_carry_bytes(g, batch) != 0);
-    out[0] = p.tz; out[1] = p.ty; out[2] = p.tx; out[3] = p.xq; out[4] = p.carry; out[5] = flat ? 1 : 0;
+    BmPlan p = {};
+    if (g.az <= 0 || g.ay <= 0 || g.ax <= 0) return p;
+    p.flat = flat_tiles<Cube, Flat>(g) ? 1 : 0;
+    const int try_ = p.flat ? Flat::TRY : Cube::TRY, trx = p.flat ? Flat::TRX : Cube::TRX;
+    p.ty = (g.ay + try_ - 1) / try_;
+    p.tx = (g.ax + trx - 1) / trx;
+    const long long cols = (long long)p.ty * p.tx * batch;          // columns of tiles: (batch element, ty, tx)
+    const int tz7 = (g.az + TCZ - 2) / (TCZ - 1), tz8 = g.az / TCZ + 1;
+    const bool slab = opt.xcd_mode != 0 && cols >= 512;
+    // The carry pays where it saves a tile per column (a 64^3 patch: 15 reference layers = 3 tiles without,
+    // 2 with) AND a slab is a couple of rounds of the 256 CUs: a tile waits for the tile below it, and when
+    // both are resident together the upper one only spins on a CU (a single small volume gains nothing).
+    const bool worth = tz8 >= 2 && tz8 < tz7 && slab;
+    // 744 KB per column (+ done[columns] + the ticket counter): beyond 16 GB the launch goes without
+    const size_t need = 2 * (size_t)cols * CARRY_TILE * sizeof(uint32_t) + ((size_t)cols + 64) * sizeof(int);
+    p.carry = (opt.carry != 0 && (worth || (opt.carry == 2 && tz8 >= 2)) && need <= ((size_t)16 << 30)) ? 1 : 0;
+    p.carry_bytes = p.carry ? need : 0;
+    p.tz = p.carry ? tz8 : tz7;
+    p.xq = (p.carry || (slab && p.tz >= 2)) ? (int)((cols + 7) / 8) : 0;
+    p.strip = (opt.xcd_mode >= 2 && p.xq) ? opt.xcd_mode : 0;
+    p.fault = opt.carry_fault;
+    return p;
 }
 
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
-                             const uint16_t* vol16, void* carry_mem) {
+                             const uint16_t* vol16, const BmPlan& p, void* carry_mem, unsigned* status) {
     // vol16 != nullptr: the volume's uint16 counts XOR 0x8000 in guarded scratch; the caller has
     // checked that the integer kernel gives the float kernel's tables (keymax <= 2^24, nx even)
-    // carry_mem: bm_carry_bytes(g, batch) of device memory, or nullptr (tiles advance by seven layers)
+    // carry_mem: p.carry_bytes of device memory when p.carry; status: the context's host-visible status word
+    if (p.carry && (!carry_mem || !status)) return hipErrorInvalidValue;
     if (!force_generic && g.az > 0 && g.ay > 0 && g.ax > 0) {
         using Cube16 = TileShape16<8, 8>;
         using Flat16 = TileShape16<4, 16>;
@@ -919,17 +933,18 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         using Flat = TileShape<4, 16>;
         static_assert(Cube::TRY == Cube16::TRY && Cube::TRX == Cube16::TRX && Flat::TRY == Flat16::TRY &&
                       Flat::TRX == Flat16::TRX, "one tile plan for both kernels");
-        const bool flat = flat_tiles<Cube, Flat>(g);
-        const TilePlan p = plan_tiles(g, batch, flat ? Flat::TRY : Cube::TRY, flat ? Flat::TRX : Cube::TRX,
-                                      carry_mem != nullptr);
+        const bool flat = p.flat != 0;
         Carry carry;
-        carry.strip = (g_bm_xcd_mode >= 2 && p.xq) ? g_bm_xcd_mode : 0;
+        carry.strip = p.strip;
         carry.on = p.carry;
         carry.buf = static_cast<uint32_t*>(carry_mem);
         const size_t cols = (size_t)p.ty * p.tx * (size_t)batch;
         carry.done = p.carry ? reinterpret_cast<int*>(carry.buf + 2 * cols * CARRY_TILE) : nullptr;
-        if (p.carry) {
-            hipError_t e = hipMemsetAsync(carry.done, 0, cols * sizeof(int), stream);
+        carry.ticket = p.carry ? carry.done + cols : nullptr;
+        carry.status = status;
+        carry.fault = p.fault;
+        if (p.carry) {      // done[columns] and the ticket counter behind it
+            hipError_t e = hipMemsetAsync(carry.done, 0, (cols + 1) * sizeof(int), stream);
             if (e != hipSuccess) return e;
         }
         dim3 grid((unsigned)(p.xq ? 8 * p.xq * p.tz : p.tz * p.ty * p.tx), (unsigned)(p.xq ? 1 : batch));

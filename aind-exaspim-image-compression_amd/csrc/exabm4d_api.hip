@@ -39,12 +39,13 @@ struct exabm4d_ctx {
     int force_generic_bm = 0;  // exabm4d_set_option("force_generic_bm")
     int bm_guarded_copy = 0;   // exabm4d_set_option("bm_guarded_copy"): staged block matching on a guarded copy
     StageOpts stage;           // exabm4d_set_option("stage_pairvol" / "stage_strip" / "stage_chunks")
+    BmOpts bm;                 // exabm4d_set_option("bm_xcd_mode" / "bm_carry" / "bm_carry_fault")
+    unsigned* status_host = nullptr;   // one pinned, device-visible word: bit 0 = a carry wait of block matching ran out
+    unsigned* status_dev = nullptr;
     int profile = 0;           // exabm4d_set_option("profile")
     int bm_int = 1;            // exabm4d_set_option("bm_int"): integer block matching on uint16 input
     int codec_version = 2;     // exabm4d_set_option("codec_version"): stream format the encoder writes
     int chunk_budget_mb = 32768;   // exabm4d_set_option("chunk_budget_mb"): scratch per batch of chunks
-    void* bm_carry = nullptr;  // block matching: the tiles' carried cell layers (bm_carry_bytes())
-    size_t bm_carry_size = 0;
     hipEvent_t ev[2 * EXABM4D_PHASE_COUNT] = {};
     bool ev_used[EXABM4D_PHASE_COUNT] = {};
     std::string err;
@@ -169,26 +170,21 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     return EXABM4D_OK;
 }
 static inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-// Block matching's carry between the tiles of a column (bm_kernels.hip, CARRY): 372 KB per column and tile
-// parity, 1 GB at 1024^3.  A context that cannot get it keeps the launch without the carry.
-static void* bm_carry_of(exabm4d_ctx* ctx, const VolGeom& g, int batch) {
-    const size_t need = bm_carry_bytes(g, batch);
-    if (need == 0) return nullptr;
-    if (need <= ctx->bm_carry_size) return ctx->bm_carry;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
-    if (ctx->bm_carry) (void)hipFree(ctx->bm_carry);
-    ctx->bm_carry = nullptr;
-    ctx->bm_carry_size = 0;
-    void* p = nullptr;
-    if (hipMalloc(&p, need) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
+// The kernels raise bits of the context's status word instead of hanging (block matching's carry: bm_kernels.hip
+// ORDER).  Looked at wherever the host has just synchronised with the context's stream.
+static int check_async_status(exabm4d_ctx* ctx) {
+    if (!ctx->status_host || *ctx->status_host == 0) return EXABM4D_OK;
+    const unsigned bits = *ctx->status_host;
+    *ctx->status_host = 0;
+    if (bits & 1u) {
+        ctx->bm.carry = 0;       // the assumption behind the carry failed on this device: do without it from now on
+        return fail(ctx, EXABM4D_ERR_HIP,
+                    "block matching: a tile waited for the tile below it longer than the poll limit (carry between "
+                    "tiles, DESIGN.md 5.1c); the match tables of the calls since the last synchronisation are void. "
+                    "The carry is now off for this context (option bm_carry = 0): repeat the call.");
     }
-    ctx->bm_carry = p;
-    ctx->bm_carry_size = need;
-    return p;
+    return fail(ctx, EXABM4D_ERR_HIP, "a kernel reported an unknown status bit");
 }
-
 
 static int make_tfdev(exabm4d_ctx* ctx, const exabm4d_transform* t, TfDev& d) {
     if (!t) return fail(ctx, EXABM4D_ERR_INVALID, "transform is NULL");
@@ -269,6 +265,15 @@ int exabm4d_create(int device, exabm4d_ctx** out) {
         return fail_hip(nullptr, e, "hipStreamCreate");
     }
     ctx->own_stream = true;
+    e = hipHostMalloc((void**)&ctx->status_host, sizeof(unsigned), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&ctx->status_dev, ctx->status_host, 0);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        if (ctx->status_host) (void)hipHostFree(ctx->status_host);
+        delete ctx;
+        return fail_hip(nullptr, e, "status word (hipHostMalloc)");
+    }
+    *ctx->status_host = 0;
     *out = ctx;
     return EXABM4D_OK;
 }
@@ -278,7 +283,7 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->bm_carry) (void)hipFree(ctx->bm_carry);
+    if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->red) (void)hipFree(ctx->red);
     if (ctx->rcp_dev) (void)hipFree(ctx->rcp_dev);
     if (ctx->codec_aux) (void)hipFree(ctx->codec_aux);
@@ -305,16 +310,16 @@ int exabm4d_reset_stream(exabm4d_ctx* ctx) {
     if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream) return EXABM4D_OK;
+    if (ctx->own_stream) return check_async_status(ctx);
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
-    return EXABM4D_OK;
+    return check_async_status(ctx);
 }
 
 int exabm4d_sync(exabm4d_ctx* ctx) {
     if (!ctx) return fail(nullptr, EXABM4D_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return EXABM4D_OK;
+    return check_async_status(ctx);
 }
 
 int exabm4d_default_params(exabm4d_params* p) {
@@ -356,11 +361,15 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     }
     if (std::strcmp(name, "bm_carry") == 0) {           // block matching: carry between the tiles of a column (0 off, 1 automatic, 2 forced)
         if (value < 0 || value > 2) return fail(ctx, EXABM4D_ERR_INVALID, "bm_carry must be 0, 1 or 2");
-        g_bm_carry = value;
+        ctx->bm.carry = value;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "bm_carry_fault") == 0) {     // debug: every carry wait counts as run out (error-path test)
+        ctx->bm.carry_fault = value ? 1 : 0;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "bm_xcd_mode") == 0) {        // block matching's workgroup order (bm_kernels.hip)
-        g_bm_xcd_mode = value < 0 ? 0 : (value > 16 ? 16 : value);   // >= 2: strips of that many tile rows
+        ctx->bm.xcd_mode = value < 0 ? 0 : (value > 16 ? 16 : value);   // >= 2: strips of that many tile rows
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "stage_strip") == 0) {        // tile-column order of the two-waves-per-group stage kernels (0 = raster, n = strips of n tile rows)
@@ -412,7 +421,7 @@ int exabm4d_memcpy_d2h(exabm4d_ctx* ctx, void* dst, const void* src, size_t byte
     if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return EXABM4D_OK;
+    return check_async_status(ctx);
 }
 int exabm4d_memset(exabm4d_ctx* ctx, void* dst, int value, size_t bytes) {
     if (!ctx || (!dst && bytes)) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
@@ -458,24 +467,24 @@ int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512) {
     make_tables((double)p->kaiser_beta, dct64, win512);
     return EXABM4D_OK;
 }
-int exabm4d_blockmatch_plan(int nz, int ny, int nx, int batch, int32_t plan[6], uint64_t* carry_bytes) {
+int exabm4d_blockmatch_plan(const exabm4d_ctx* ctx, int nz, int ny, int nx, int batch, int32_t plan[6],
+                            uint64_t* carry_bytes) {
     if (!plan || !carry_bytes) return EXABM4D_ERR_INVALID;
     VolGeom g;
     const int rc = make_geom(nullptr, nz, ny, nx, batch, g);
     if (rc) return rc;
-    int out[6];
-    bm_plan(g, batch, out);
-    for (int i = 0; i < 6; i++) plan[i] = out[i];
-    *carry_bytes = (uint64_t)bm_carry_bytes(g, batch);
+    const BmPlan p = bm_plan(g, batch, ctx ? ctx->bm : BmOpts());
+    plan[0] = p.tz; plan[1] = p.ty; plan[2] = p.tx; plan[3] = p.xq; plan[4] = p.carry; plan[5] = p.flat;
+    *carry_bytes = (uint64_t)p.carry_bytes;
     return EXABM4D_OK;
 }
 
 // Scratch layout of one pipeline run (run_pipeline below walks it in this order)
 namespace {
 struct PipeLayout {
-    size_t keys, num, basic, cw, tmp, pair, qscale, maxbits, total;
+    size_t keys, num, basic, cw, tmp, pair, qscale, maxbits, carry, total;
 };
-PipeLayout pipe_layout(size_t n, size_t nref, int batch, int stages) {
+PipeLayout pipe_layout(size_t n, size_t nref, int batch, int stages, size_t carry_bytes) {
     PipeLayout L;
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at += align256(bytes); return o; };
@@ -487,16 +496,21 @@ PipeLayout pipe_layout(size_t n, size_t nref, int batch, int stages) {
     L.pair = take(stages >= 2 ? 2 * n * sizeof(float) : 0);     // interleaved (noisy, basic) volume of the Wiener gathers
     L.qscale = take((size_t)batch * 2 * sizeof(double));
     L.maxbits = take((size_t)batch * sizeof(unsigned));
+    L.carry = take(carry_bytes);                                // block matching's carry between tiles (BmPlan)
     L.total = at;
     return L;
 }
 }  // namespace
 
+// scratch of one pipeline run under the given block-matching options (the carry's memory depends on them)
+static size_t pipe_bytes(const BmOpts& bm, int nz, int ny, int nx, int batch, int stages) {
+    VolGeom g;
+    if (make_geom(nullptr, nz, ny, nx, batch, g) != EXABM4D_OK) return 0;
+    return pipe_layout((size_t)g.nvox * (size_t)batch, (size_t)g.nref * (size_t)batch, batch, stages,
+                       bm_plan(g, batch, bm).carry_bytes).total;
+}
 size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages) {
-    if (nz < 8 || ny < 8 || nx < 8 || batch < 1) return 0;
-    const size_t n = (size_t)nz * ny * nx * (size_t)batch;
-    const size_t nref = (size_t)grid_count(nz) * grid_count(ny) * grid_count(nx) * (size_t)batch;
-    return pipe_layout(n, nref, batch, stages).total;
+    return pipe_bytes(BmOpts(), nz, ny, nx, batch, stages);     // default options; includes the carry (round 4)
 }
 
 // ---- staged entry points ---------------------------------------------------------------------------------
@@ -510,11 +524,12 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
     rc = make_geom(ctx, nz, ny, nx, batch, g);
     if (rc) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const BmPlan plan = bm_plan(g, batch, ctx->bm);
     if (ctx->bm_guarded_copy) {
         // parity hook for the pipeline's path: match on a copy inside the scratch allocation, with
         // 256 bytes of poison on either side, through the kernel's `guarded` variant
         const size_t bytes = (size_t)g.nvox * (size_t)batch * sizeof(float);
-        rc = ensure_scratch(ctx, bytes + 512);
+        rc = ensure_scratch(ctx, align256(bytes + 512) + plan.carry_bytes);
         if (rc) return rc;
         char* base = static_cast<char*>(ctx->scratch);
         if (!guarded_region_ok(ctx, base + 256, bytes))
@@ -523,11 +538,14 @@ int exabm4d_blockmatch_dev(exabm4d_ctx* ctx, const float* vol, int nz, int ny, i
         HIP_TRY(ctx, hipMemcpyAsync(base + 256, vol, bytes, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(ctx, launch_blockmatch(reinterpret_cast<const float*>(base + 256), g, batch,
                                        keymax_of(sigma, c_match), keys, ctx->stream,
-                                       ctx->force_generic_bm, 1, nullptr, bm_carry_of(ctx, g, batch)));
+                                       ctx->force_generic_bm, 1, nullptr, plan, base + align256(bytes + 512),
+                                       ctx->status_dev));
         return EXABM4D_OK;
     }
+    rc = ensure_scratch(ctx, plan.carry_bytes);
+    if (rc) return rc;
     HIP_TRY(ctx, launch_blockmatch(vol, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm, 0, nullptr, bm_carry_of(ctx, g, batch)));
+                                   ctx->force_generic_bm, 0, nullptr, plan, ctx->scratch, ctx->status_dev));
     return EXABM4D_OK;
 }
 
@@ -546,7 +564,9 @@ int exabm4d_blockmatch_u16_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, in
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)g.nvox * (size_t)batch;
     const size_t fbytes = align256(n * sizeof(float));
-    rc = ensure_scratch(ctx, 2 * GUARD_BYTES + fbytes + align256(n * sizeof(uint16_t)));
+    const BmPlan plan = bm_plan(g, batch, ctx->bm);
+    const size_t vols = align256(2 * GUARD_BYTES + fbytes + align256(n * sizeof(uint16_t)) + GUARD_BYTES);
+    rc = ensure_scratch(ctx, vols + plan.carry_bytes);
     if (rc) return rc;
     char* base = static_cast<char*>(ctx->scratch);
     float* f32 = reinterpret_cast<float*>(base + GUARD_BYTES);
@@ -558,7 +578,7 @@ int exabm4d_blockmatch_u16_dev(exabm4d_ctx* ctx, const uint16_t* vol, int nz, in
     if (!guarded_region_ok(ctx, f32, n * sizeof(float)))
         return fail(ctx, EXABM4D_ERR_INVALID, "internal: guarded volume without mapped slack around it");
     HIP_TRY(ctx, launch_blockmatch(f32, g, batch, keymax_of(sigma, c_match), keys, ctx->stream,
-                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr, bm_carry_of(ctx, g, batch)));
+                                   ctx->force_generic_bm, 1, use16 ? u16 : nullptr, plan, base + vols, ctx->status_dev));
     return EXABM4D_OK;
 }
 
@@ -688,7 +708,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     // data_exp: E of the numerator's unit: 17 from the uint16 entry points,
     // EXABM4D_DATA_EXP_AUTO (from every volume's largest |v|) from the fp32 ones.
     const size_t n = (size_t)g.nvox * (size_t)batch;
-    const PipeLayout L = pipe_layout(n, (size_t)g.nref * (size_t)batch, batch, stages);
+    const BmPlan plan = bm_plan(g, batch, ctx->bm);           // one plan for both matching launches
+    const PipeLayout L = pipe_layout(n, (size_t)g.nref * (size_t)batch, batch, stages, plan.carry_bytes);
     uint32_t* keys = reinterpret_cast<uint32_t*>(scratch + L.keys);
     long long* num = reinterpret_cast<long long*>(scratch + L.num);
     float* basic = reinterpret_cast<float*>(scratch + L.basic);  // only touched when stages >= 2
@@ -721,8 +742,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
                            offset_exact_in_fp32(u16_offset) &&
                            guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
         HIP_TRY(ctx, launch_blockmatch(noisy, g, batch, keymax_of(sigma, p->c_match_ht), keys, s,
-                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr,
-                                       bm_carry_of(ctx, g, batch)));
+                                       ctx->force_generic_bm, noisy_guarded, use16 ? noisy16 : nullptr, plan,
+                                       scratch + L.carry, ctx->status_dev));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_HT);
@@ -746,7 +767,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
             HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys,
-                                           s, ctx->force_generic_bm, 1, nullptr, bm_carry_of(ctx, g, batch)));
+                                           s, ctx->force_generic_bm, 1, nullptr, plan, scratch + L.carry,
+                                           ctx->status_dev));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_STAGE_WIE);
@@ -782,7 +804,7 @@ int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int n
     VolGeom g;
     int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
     if (rc) return rc;
-    rc = ensure_scratch(ctx, exabm4d_scratch_bytes(nz, ny, nx, batch, stages));
+    rc = ensure_scratch(ctx, pipe_bytes(ctx->bm, nz, ny, nx, batch, stages));
     if (rc) return rc;
     return run_pipeline(ctx, in, out, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
                         static_cast<char*>(ctx->scratch), 0, EXABM4D_DATA_EXP_AUTO);
@@ -797,7 +819,7 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
     const size_t n = (size_t)g.nvox * (size_t)batch;
     if (!(std::fabs(offset) <= 65536.0f))     // |v - offset| < 2^17: the fixed unit of the uint16 pipelines
         return fail(ctx, EXABM4D_ERR_INVALID, "offset must lie within [-65536, 65536]");
-    const size_t base = exabm4d_scratch_bytes(nz, ny, nx, batch, stages);
+    const size_t base = pipe_bytes(ctx->bm, nz, ny, nx, batch, stages);
     const size_t fbytes = align256(n * sizeof(float));
     rc = ensure_scratch(ctx, base + fbytes + GUARD_BYTES + align256(n * sizeof(uint16_t)));
     if (rc) return rc;
@@ -852,7 +874,7 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                 cb.sgy = ry.count; cb.sgx = rx.count;
                 cb.out_z0 = zc0;
                 const long long nchunks = (long long)rz.count * ry.count * rx.count;
-                const size_t per = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, 1, stages) +
+                const size_t per = pipe_bytes(ctx->bm, cb.pz, cb.py, cb.px, 1, stages) +
                                    align256((size_t)cb.pz * cb.py * cb.px * (sizeof(float) + sizeof(uint16_t)));
                 long long bmax = (long long)(((size_t)ctx->chunk_budget_mb << 20) / per);
                 if (bmax < 1) bmax = 1;
@@ -865,7 +887,7 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                     rc = make_geom(ctx, cb.pz, cb.py, cb.px, count, g);
                     if (rc) return rc;
                     const size_t n = (size_t)g.nvox * (size_t)count;
-                    const size_t base = exabm4d_scratch_bytes(cb.pz, cb.py, cb.px, count, stages);
+                    const size_t base = pipe_bytes(ctx->bm, cb.pz, cb.py, cb.px, count, stages);
                     const size_t fbytes = align256(n * sizeof(float));
                     rc = ensure_scratch(ctx, base + fbytes + GUARD_BYTES + align256(n * sizeof(uint16_t)));
                     if (rc) return rc;
@@ -1036,7 +1058,7 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
     (void)hipStreamSynchronize(ctx->stream);
     release();
     if (st.failed) return fail(ctx, rc ? rc : EXABM4D_ERR_HIP, "streamed chunk mode: " + st.err);
-    return EXABM4D_OK;
+    return check_async_status(ctx);
 }
 
 int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
@@ -1046,18 +1068,23 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
     if (rc) return rc;
     const size_t n = (size_t)g.nvox * (size_t)batch;
-    const size_t base = exabm4d_scratch_bytes(nz, ny, nx, batch, stages);
-    rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
-    if (rc) return rc;
-    char* scratch = static_cast<char*>(ctx->scratch);
-    float* vol = reinterpret_cast<float*>(scratch + base);
-    HIP_TRY(ctx, hipMemcpyAsync(vol, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
-                      scratch, 1, EXABM4D_DATA_EXP_AUTO);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return EXABM4D_OK;
+    // This call owns its input and synchronises, so a run whose carry wait ran out (check_async_status) is
+    // simply repeated without the carry: the caller of bm4d(raw, sigma) sees a result, never a hang or a retry.
+    for (int attempt = 0;; attempt++) {
+        const size_t base = pipe_bytes(ctx->bm, nz, ny, nx, batch, stages);
+        rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+        if (rc) return rc;
+        char* scratch = static_cast<char*>(ctx->scratch);
+        float* vol = reinterpret_cast<float*>(scratch + base);
+        HIP_TRY(ctx, hipMemcpyAsync(vol, in, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
+                          scratch, 1, EXABM4D_DATA_EXP_AUTO);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        rc = check_async_status(ctx);
+        if (rc == EXABM4D_OK || attempt == 1 || ctx->bm.carry != 0) return rc;
+    }
 }
 
 int exabm4d_profile_read(exabm4d_ctx* ctx, float* ms, int max_phases) {

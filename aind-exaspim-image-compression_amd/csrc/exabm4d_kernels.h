@@ -56,13 +56,25 @@ int ssim3d_partials(int nz, int ny, int nx);
 int ssim3d_max_window();
 hipError_t launch_ssim3d(const void* a, const void* b, int dtype, int nz, int ny, int nx, int w,
                          double C1, double C2, double* partials, double* out1, hipStream_t s);
-extern int g_bm_xcd_mode;    // block matching's workgroup order: 0 = contiguous per XCD, 1 = all XCDs in one z slab of tiles (raster), n >= 2 = in strips of n tile rows
-extern int g_bm_carry;       // block matching: tiles of a column hand their top cell layer upwards (0 off, 1 automatic, 2 forced)
-void bm_plan(const VolGeom& g, int batch, int out[6]);   // {tz, ty, tx, slab-order q, carry, flat}: the launch plan (host logic)
-size_t bm_carry_bytes(const VolGeom& g, int batch);   // device memory launch_blockmatch needs for that (0: launch without)
+// Options of block matching (per context since round 4; exabm4d_set_option "bm_xcd_mode" / "bm_carry" / "bm_carry_fault")
+struct BmOpts {
+    int xcd_mode = 2;       // workgroup order: 0 = contiguous per XCD, 1 = all XCDs in one z slab of tiles (raster), n >= 2 = in strips of n tile rows
+    int carry = 1;          // tiles of a column hand their top cell layer upwards (0 off, 1 automatic, 2 forced)
+    int carry_fault = 0;    // debug: every carry wait counts as run out (the error path's test)
+};
+// The launch block matching chooses for a geometry (bm_kernels.hip: bm_plan), evaluated once per launch
+struct BmPlan {
+    int tz, ty, tx;         // tile slabs, tile rows, tile columns
+    int xq;                 // slab-order parameter (0: every XCD walks its own contiguous range)
+    int carry;              // carry between the tiles of a column on
+    int flat;               // 4 x 16 tile shape instead of 8 x 8
+    int strip, fault;
+    size_t carry_bytes;     // device memory the launch needs for the carry (slots + done[] + ticket), 0 without
+};
+BmPlan bm_plan(const VolGeom& g, int batch, const BmOpts& opt);
 hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint32_t keymax,
                              uint32_t* keys, hipStream_t stream, int force_generic, int guarded,
-                             const uint16_t* vol16 = nullptr, void* carry_mem = nullptr);
+                             const uint16_t* vol16, const BmPlan& plan, void* carry_mem, unsigned* status);
 // Options of the stage kernels (per context since round 4; exabm4d_set_option "stage_pairvol" / "stage_strip" /
 // "stage_chunks"): Wiener gathers from an interleaved (noisy, basic) volume; tile columns walked in strips of n
 // tile rows (0 = raster); diagnostic override of the z chunk count (0 = automatic).

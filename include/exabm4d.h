@@ -123,8 +123,12 @@ int exabm4d_default_params(exabm4d_params* p);
  * chunk-local mode, per-phase HIP events for exabm4d_profile_read.  "bm_carry" = 0 | 1 | 2 (default 1):
  * block matching's tiles hand their top cell layer to the tile above through device memory, eight
  * reference layers per tile instead of seven (1: where it saves a tile per column and the launch is large
- * enough, 2: wherever a column has two tiles; needs 744 KB of device memory per tile column, allocated on
- * first use; tables are identical); "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
+ * enough, 2: wherever a column has two tiles; needs 744 KB of the context's scratch per tile column; tables
+ * are identical).  A tile waits for the tile below it; workgroups take their tiles by ticket,
+ * so the wait always ends, and it is bounded besides: should it ever run out, the kernel raises a status word
+ * instead of hanging, the next synchronising call (exabm4d_sync, exabm4d_memcpy_d2h, *_host, ...) returns
+ * EXABM4D_ERR_HIP, and the carry is off for that context from then on (exabm4d_denoise_f32_host repeats its
+ * run without the carry by itself).  "bm_carry_fault" = 1 (debug) makes every such wait count as run out; "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
  * block matching; "stage_strip" = 0 | n (default 3): tile-column order of the stage
  * kernels (0 = raster, n = strips of n tile rows; the same results, bit for bit: the sums are integers).
  * Every option belongs to the context it is set on (round 4; rounds 1-3 kept some in process globals). */
@@ -167,14 +171,18 @@ int exabm4d_grid_positions(int n, int32_t* pos);
 /* The constant tables the kernels use: orthonormal DCT-II 8x8 (row u, col n) and the 8^3
  * aggregation window (z,y,x raster). Computed in double, rounded once to fp32. */
 int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512);
-/* Bytes of device scratch a denoise call of this shape needs (match table + num/den + basic). */
+/* Bytes of device scratch an exabm4d_denoise_*_dev call of this shape takes from the context (match table,
+ * 64-bit numerator and corner-weight sums, basic estimate, work volumes, and -- since round 4 -- the 744 KB per
+ * tile column of block matching's carry where the default options use it: 1.0 GB of 27 GB at 1024^3), under
+ * the default options; the uint16 entry points add the fp32 + uint16 counts (6 bytes per voxel). */
 size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages);
 
 /* The launch block matching chooses for a geometry (host logic only, no device call): plan = {tile slabs in z,
  * tile rows, tile columns, slab-order parameter (0: every XCD walks its own contiguous range), carry between
- * tiles on, flat 4 x 16 tile shape}; carry_bytes = device memory the context allocates for
- * the carry (0 without).  Follows the process-wide options "bm_carry" / "bm_xcd_mode". */
-int exabm4d_blockmatch_plan(int nz, int ny, int nx, int batch, int32_t plan[6], uint64_t* carry_bytes);
+ * tiles on, flat 4 x 16 tile shape}; carry_bytes = the part of the context's scratch the
+ * carry takes (0 without).  Follows ctx's options "bm_carry" / "bm_xcd_mode"; ctx == NULL: the defaults. */
+int exabm4d_blockmatch_plan(const exabm4d_ctx* ctx, int nz, int ny, int nx, int batch, int32_t plan[6],
+                            uint64_t* carry_bytes);
 
 /* ---- BM4D staged entry points (parity hooks; a-B1 .. a-B6 of SURVEY.md section 8) ---------- */
 /* Block matching.  keys: [batch][nref][16] uint32, nref = gz*gy*gx in (z,y,x) raster of the

@@ -124,3 +124,48 @@ def test_chunk_local_mode_with_and_without_the_carry(ctx, carry):
     want = denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8)
     carry(2)
     np.testing.assert_array_equal(denoise_chunked(vol, SIGMA, 37.0, chunk=40, halo=8), want)
+
+
+def test_a_carry_wait_that_runs_out_is_an_error_not_a_hang(ctx, oracle, carry):
+    """Round 4: tiles take their place in the launch order by ticket, so a tile's producer has always started
+    and the wait ends; it is bounded all the same.  The debug option "bm_carry_fault" makes every wait count
+    as run out: the launch finishes (void tables), the next synchronising call reports EXABM4D_ERR_HIP and
+    names the carry, the context switches the carry off and works -- and the bm4d() path
+    (exabm4d_denoise_f32_host) repeats its run without the carry by itself."""
+    vol = synth_volume((100, 40, 44), seed=5, as_u16=True)[0]
+    f = vol.astype(np.float32) - np.float32(37.0)
+    want = oracle.blockmatch(f, SIGMA, 3.0)
+    carry(2)
+    assert _native.blockmatch_plan(vol.shape, ctx=ctx)["carry"]
+    ctx.set_option("bm_carry_fault", 1)
+    try:
+        with pytest.raises(_native.NativeError, match="carry"):
+            _keys(ctx, vol, 3.0, False)                       # ctx.sync() inside sees the status word
+        assert not _native.blockmatch_plan(vol.shape, ctx=ctx)["carry"]          # off for this context now
+        np.testing.assert_array_equal(_keys(ctx, vol, 3.0, False), want)         # and the context works
+        carry(2)                                              # forced again, fault still armed: the host entry recovers
+        got = ctx.denoise_f32_host(f, SIGMA, stages=1)
+        np.testing.assert_array_equal(got, oracle.bm4d(f, SIGMA, stages=1))
+        assert not _native.blockmatch_plan(vol.shape, ctx=ctx)["carry"]
+    finally:
+        ctx.set_option("bm_carry_fault", 0)
+    carry(2)
+    np.testing.assert_array_equal(_keys(ctx, vol, 3.0, False), want)             # the carry itself is intact
+
+
+def test_options_belong_to_their_context(ctx):
+    """Round 4 (ADVICE): bm_carry / bm_xcd_mode / stage_* used to be process globals behind a per-context
+    setter.  A second context on the same device keeps the defaults whatever the first one sets."""
+    other = _native.Context(0)
+    try:
+        ctx.set_option("bm_carry", 0)
+        assert not _native.blockmatch_plan((1024, 1024, 1024), ctx=ctx)["carry"]
+        assert _native.blockmatch_plan((1024, 1024, 1024), ctx=other)["carry"]
+        assert _native.blockmatch_plan((1024, 1024, 1024))["carry"]
+        ctx.set_option("bm_xcd_mode", 0)
+        assert _native.blockmatch_plan((64, 640, 640), ctx=ctx)["slab_order_q"] == 0
+        assert _native.blockmatch_plan((64, 640, 640), ctx=other)["slab_order_q"] > 0
+    finally:
+        ctx.set_option("bm_carry", 1)
+        ctx.set_option("bm_xcd_mode", 2)
+        other.close()
