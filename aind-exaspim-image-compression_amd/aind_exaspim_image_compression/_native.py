@@ -595,11 +595,12 @@ os.register_at_fork(after_in_child=_after_fork_in_child)
 
 
 def context(device=None):
-    """The calling process's context for ``device`` (default: LOCAL_RANK or 0), created lazily.
+    """The calling process's context for ``device`` (default: ``default_device()`` -- EXABM4D_DEVICE,
+    LOCAL_RANK, or this pool worker's index mod the device count), created lazily.
 
     A context inherited through fork() is never reused: HIP state does not survive fork."""
     if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
+        device = default_device()
     global _hip_owner_pid
     if _forked_from_hip_parent:
         raise NativeError(
@@ -664,6 +665,61 @@ def device_count():
     if _hip_owner_pid is None:
         _hip_owner_pid = os.getpid()
     return n
+
+
+def device_count_no_init():
+    """Number of GPUs this process would see, WITHOUT initialising the HIP runtime (a parent that is about to
+    fork workers must not, see ``context``): the visibility lists HIP honours if one is set, else the KFD
+    topology (nodes with SIMDs are GPUs).  0 when neither says anything."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for node in os.listdir(root):
+            try:
+                with open(os.path.join(root, node, "properties")) as f:
+                    props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return 0
+    return n
+
+
+def worker_index():
+    """0-based index of this process among its parent's pool workers (``multiprocessing`` numbers the
+    processes it starts: ``current_process()._identity`` -- what ``ProcessPoolExecutor`` workers carry), or
+    None for a process nobody numbered (the main process, a plain ``os.fork``)."""
+    try:
+        import multiprocessing
+        ident = multiprocessing.current_process()._identity
+        return int(ident[-1]) - 1 if ident else None
+    except Exception:
+        return None
+
+
+def default_device(count=None):
+    """The device of a caller that named none: ``EXABM4D_DEVICE`` if set; else ``LOCAL_RANK`` (one process
+    per GPU under torch.distributed.run); else -- the reference's worker pattern, a pool of forked workers
+    that each call ``bm4d()`` (scripts/precompute.py:215-228) -- worker index mod device count, so that a
+    pool spreads over the node's GPUs instead of piling onto device 0; a process without a worker index
+    (the main process) gets 0.  ``count``: the device count to use (tests); default ``device_count_no_init()``."""
+    v = os.environ.get("EXABM4D_DEVICE")
+    if v not in (None, ""):
+        return int(v)
+    v = os.environ.get("LOCAL_RANK")
+    if v not in (None, ""):
+        return int(v)
+    idx = worker_index()
+    if idx is None:
+        return 0
+    n = device_count_no_init() if count is None else int(count)
+    return idx % n if n > 0 else 0
 
 
 # -- host-only helpers (no GPU) -----------------------------------------------------------------

@@ -7,6 +7,12 @@ ProcessPoolExecutor whose workers each call bm4d(raw, sigma) on one 64^3 patch
                                                3 patches -> teachers saved to out.npy
     python fork_workers.py dirty               parent initialises HIP first, then forks: the
                                                worker must raise NativeError (exit code 0 if it did)
+    python fork_workers.py broker <out.npy> [workers=8] [patches=24]
+                                               EXABM4D_BROKER=1: the forked workers never touch the GPU, one
+                                               owner process coalesces their single-patch calls
+    python fork_workers.py devices <out.npy> <d0,d1,..> [patches=12]
+                                               denoise_patches(batch, devices=[...]) from a parent that never
+                                               touches the GPU
 """
 import multiprocessing
 import os
@@ -51,6 +57,28 @@ def main():
         pids = {pid for pid, _ in res}
         assert os.getpid() not in pids and 1 <= len(pids) <= 2
         np.save(sys.argv[2], np.stack([t for _, t in res]))
+        return 0
+    if mode == "broker":
+        workers = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+        n = int(sys.argv[4]) if len(sys.argv) > 4 else 24
+        os.environ["EXABM4D_BROKER"] = "1"
+        os.environ["EXABM4D_BROKER_IDLE"] = "2"
+        with ProcessPoolExecutor(max_workers=workers, mp_context=fork) as pool:
+            res = list(pool.map(teacher, range(n)))
+        assert os.getpid() not in {pid for pid, _ in res}
+        np.save(sys.argv[2], np.stack([t for _, t in res]))
+        from aind_exaspim_image_compression import _native
+        assert _native._hip_owner_pid is None         # neither the parent ...
+        return 0
+    if mode == "devices":
+        devices = [int(d) for d in sys.argv[3].split(",")]
+        n = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+        from aind_exaspim_image_compression import _native
+        from aind_exaspim_image_compression.bm4d import denoise_patches
+        batch = np.stack([patch(i) for i in range(n)])
+        out = denoise_patches(batch, SIGMA, devices=devices)
+        assert _native._hip_owner_pid is None         # the parent stayed off the GPU
+        np.save(sys.argv[2], out)
         return 0
     if mode == "dirty":
         from aind_exaspim_image_compression import _native
