@@ -219,12 +219,60 @@ def cpu_baseline(seed, budget_s=30.0):
                   f"fully: {c2_all['seconds']} s on {usable} threads",
         "cpu_model": model,
         "cpus_visible": visible,
+        # what the job may use of the box: quote the GPU / CPU ratio as "vs `cores` threads of the PORT", a
+        # whole-box run of the port would be several times faster
+        "share_of_box": round(usable / max(visible, 1), 4),
+        "share_note": f"{usable} of {visible} visible CPUs are usable by this job (cgroup / affinity); "
+                      "GPU / CPU ratios are against these threads of the port, never the reference",
         "c1_64_all_threads": c1_all,
         "c1_64_one_thread": c1_one,
         "c2_256_all_threads": c2_all,
         "one_thread_large": c2_one,
         "encode": cpu_encode_baseline(port256, usable),
     }
+
+
+def end_to_end_leg(ctx, vol, d_in, d_out, params, stages):
+    """host array -> host array for the bench volume, outside `value`.  (a) the three legs one
+    after the other: H2D of the uint16 input, the denoise call, D2H of the uint16 output (pageable host
+    arrays, as numpy hands them over; the destination is touched beforehand so that page faults are not
+    timed); (b) the overlapped form a host caller would use for a volume of this size,
+    exabm4d_denoise_chunked_u16_host (256^3 cores + 8-voxel halo, BASELINE config 4's chunk-local semantics:
+    layers of chunks go up and come down while the neighbouring layer is in the kernels)."""
+    import ctypes
+    lib = _native.lib()
+    out = np.zeros(vol.shape, dtype=np.uint16)
+    shape, n = vol.shape, vol.size
+    ctx.sync()
+    t0 = time.perf_counter()
+    d_in.upload(vol)                                       # exabm4d_memcpy_h2d synchronises
+    t1 = time.perf_counter()
+    ctx.denoise_u16(d_in, d_out, shape, SIGMA, OFFSET, params=params, stages=stages)
+    ctx.sync()
+    t2 = time.perf_counter()
+    ctx._check(lib.exabm4d_memcpy_d2h(ctx.handle, out.ctypes.data_as(ctypes.c_void_p), d_out.ptr, out.nbytes))
+    t3 = time.perf_counter()
+    res = {
+        "volume": list(shape),
+        "h2d_ms": 1e3 * (t1 - t0), "denoise_ms": 1e3 * (t2 - t1), "d2h_ms": 1e3 * (t3 - t2),
+        "sequential_ms": 1e3 * (t3 - t0), "sequential_voxels_per_s": n / (t3 - t0),
+        "h2d_GBs": vol.nbytes / (t1 - t0) / 1e9, "d2h_GBs": out.nbytes / (t3 - t2) / 1e9,
+        "host_memory": "pageable numpy arrays",
+        "note": "PCIe-inclusive, never the bench `value`; denoise only (the encode legs' output stays in HBM)",
+    }
+    try:
+        out2 = np.zeros(vol.shape, dtype=np.uint16)
+        t0 = time.perf_counter()
+        ctx.denoise_chunked_u16_host(vol, out2, SIGMA, OFFSET, chunk=256, halo=8, params=params, stages=stages)
+        dt = time.perf_counter() - t0
+        res["streamed_chunk_local"] = {
+            "ms": 1e3 * dt, "voxels_per_s": n / dt,
+            "what": "exabm4d_denoise_chunked_u16_host: 256^3 cores + 8 halo, uploads / downloads of the "
+                    "neighbouring chunk layers under the kernels (1.2 x the voxels of the whole-volume call)",
+        }
+    except Exception as e:                               # the metric line must not die with the extra leg
+        res["streamed_chunk_local"] = {"error": repr(e)}
+    return res
 
 
 def cpu_encode_baseline(den, threads):
@@ -615,6 +663,9 @@ def main():
                          "halo), raw-input halo exchange only")
     ap.add_argument("--no-encode", action="store_true",
                     help="time the denoiser alone (the metric's step includes the encode legs)")
+    ap.add_argument("--end-to-end", type=int, default=1,
+                    help="0: skip the host-to-host legs (H2D + denoise + D2H, and the streamed chunk-local call) "
+                         "reported next to `value` at N = 1")
     ap.add_argument("--cpu-sample", type=int, default=1,
                     help="0 disables the CPU-baseline leg (C1 64^3 and C2 256^3 timed fully on the host)")
     ap.add_argument("--bm4dnet", type=int, default=1,
@@ -857,6 +908,8 @@ def main():
         }
         if encoded is not None:
             result["encoded"] = encoded
+        if args.end_to_end and world == 1:
+            result["end_to_end"] = end_to_end_leg(ctx, vol, d_in, d_out, params, args.stages)
         if args.cpu_sample > 0 and world == 1:         # reported baseline: rank 0 at N = 1 only
             port256, result["cpu_baseline"] = cpu_baseline(seed=1000)
             # PSNR (BASELINE.json's metric names it): GPU and CPU port on the SAME 256^3 volume

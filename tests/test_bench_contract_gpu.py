@@ -39,6 +39,12 @@ def test_default_line_has_the_contract_keys():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] == "port" and c["value"] > 0
+    assert 0 < c["share_of_box"] <= 1 and c["cores"] <= c["cpus_visible"]
+    # the PCIe-inclusive figures ride with the line, outside `value`
+    e = d["end_to_end"]
+    assert e["h2d_ms"] > 0 and e["denoise_ms"] > 0 and e["d2h_ms"] > 0
+    assert abs(e["sequential_ms"] - (e["h2d_ms"] + e["denoise_ms"] + e["d2h_ms"])) < 1e-6 * e["sequential_ms"] + 1e-3
+    assert e["streamed_chunk_local"]["ms"] > 0
     # "denoised+encoded": the encode legs are inside the timed step
     for phase in ("blockmatch_ht", "stage_ht", "blockmatch_wie", "stage_wie", "encode_u16", "dct_quantise",
                   "encode_idx"):

@@ -3,7 +3,7 @@
 size=$1; shift
 for v in "$@"; do
   if [ "$v" = default ]; then unset EXABM4D_LIB; else export EXABM4D_LIB=$PWD/tools/dbg/variants/libexabm4d_$v.so; fi
-  python bench.py --size $size --steps 3 --warmup 1 --cpu-sample 0 --bm4dnet 0 --no-encode > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_$v.err; continue; }
+  python bench.py --size $size --steps 3 --warmup 1 --cpu-sample 0 --bm4dnet 0 --end-to-end 0 --no-encode > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { echo "$v FAILED"; tail -3 gpurun_out/ab_$v.err; continue; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/ab_$v.json"))
