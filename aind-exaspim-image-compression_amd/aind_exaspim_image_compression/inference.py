@@ -38,6 +38,56 @@ def _model_device(model):
     return dev
 
 
+_MIOPEN_DONE = False
+
+
+def _miopen_defaults():
+    """Once per process, before its first convolution (``predict`` / ``load_model`` call it): make MIOpen
+    pick the tuned solvers for the BM4DNet U-Net without a search.
+      * a per-user MIOpen user-db directory (``$XDG_CACHE_HOME/exabm4d/miopen/torch-<version>``) seeded with
+        the find-db records shipped in ``miopen_db/`` (12 KB of text MIOpen wrote during one exhaustive
+        search on an MI355X) -- unless the caller already chose ``MIOPEN_USER_DB_PATH``; searches the caller
+        runs later (``tune_model``) persist there too, so they are paid once per machine, not per process;
+      * ``MIOPEN_FIND_MODE=2`` (FAST) unless the caller set the variable: a find-db hit selects the recorded
+        solver at once, a miss falls back to heuristics instead of timing every solver (17 s per process
+        for this network in the default mode).
+    ``EXABM4D_MIOPEN_DEFAULTS=0`` leaves MIOpen's environment alone.  Measured (tools/dbg/miopen_cache_probe.sh,
+    U-Net forward 32 x 64^3 fp32): with the records first call 0.1 s, then 68 ms (51 TFLOP/s); without them
+    and without this function 15 s, then 116 ms (30 TFLOP/s)."""
+    global _MIOPEN_DONE
+    if _MIOPEN_DONE:
+        return
+    _MIOPEN_DONE = True
+    if os.environ.get("EXABM4D_MIOPEN_DEFAULTS", "1") == "0":
+        return
+    if "MIOPEN_USER_DB_PATH" not in os.environ:
+        import shutil
+        base = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"),
+                            "exabm4d", "miopen", "torch-" + torch.__version__.replace("+", "_"))
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "miopen_db")
+        try:
+            os.makedirs(os.path.join(base, "db"), exist_ok=True)
+            os.makedirs(os.path.join(base, "kernels"), exist_ok=True)
+            for name in os.listdir(src):
+                dst = os.path.join(base, "db", name)
+                if name.endswith(".txt") and not os.path.exists(dst):
+                    shutil.copyfile(os.path.join(src, name), dst)
+            os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(base, "db")
+            os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", os.path.join(base, "kernels"))
+        except OSError:
+            pass                                   # read-only home: MIOpen's own defaults, FAST mode below
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
+
+def _ndhwc_shadow(model):
+    """An NDHWC (channels_last_3d) copy of an eval-mode fp32 module for the forward passes of one ``predict``
+    call: MIOpen's implicit-GEMM solvers for NDHWC weights run this U-Net at 51 TFLOP/s against 30 for the
+    default layout.  The caller's model is not touched (52 MB copied per call); same fp32 arithmetic, results
+    differ by summation order (4e-6 on the golden patch, tests at 2e-3)."""
+    import copy
+    return copy.deepcopy(model).to(memory_format=torch.channels_last_3d)
+
+
 def tune_model(model):
     """Opt-in MIOpen tuning for the BM4DNet stage on MI355X: NDHWC weights + exhaustive solver
     search (``torch.backends.cudnn.benchmark``, process-wide).  U-Net forward, 32 x 64^3 fp32:
@@ -68,13 +118,16 @@ def quick_start(model):
 
 
 def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, trim=5,
-            verbose=True):
+            verbose=True, fast=True):
     """Denoise a 3-D image by overlapping-patch inference; returns uint16 counts.
 
     Parameters follow the reference (inference.py:28-67): ``img`` is a 3-D array (leading
     singleton axes are accepted), ``model`` a torch module (or any callable on a
     ``(B,1,P,P,P)`` float32 CUDA tensor), ``transform`` the IntensityTransform the model was
-    trained with."""
+    trained with.  ``fast`` (not in the reference; default on): an eval-mode ``nn.Module`` runs its forward
+    passes through an NDHWC copy of itself with MIOpen's tuned solvers (``_miopen_defaults``,
+    ``_ndhwc_shadow``; fp32 throughout); ``fast=False`` calls ``model`` exactly as given."""
+    _miopen_defaults()
     img = np.asarray(img)
     while img.ndim > 3:
         if img.shape[0] != 1:
@@ -86,6 +139,10 @@ def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, tri
     n = int(np.prod(shape))
     dev = _model_device(model)
     ctx = _native.context(dev.index or 0)
+    run = model
+    if fast and isinstance(model, torch.nn.Module) and not model.training and \
+            all(p.dtype == torch.float32 for p in model.parameters()) and any(True for _ in model.parameters()):
+        run = _ndhwc_shadow(model)
 
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev)
@@ -116,7 +173,7 @@ def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, tri
             # whose output rows do not depend on the rest of the batch.
             full = nb < batch_size and b0 > 0 and not getattr(model, "training", True)
             with torch.no_grad():
-                out = model(batch if full else batch[:nb])[:nb]        # inference.py:171-173
+                out = run(batch if full else batch[:nb])[:nb]          # inference.py:171-173
             out = out.to(torch.float32).contiguous()
             ctx.tile_accumulate(out, chunk, patch_size, trim, accum_pred, accum_wgt, shape)
             if pbar is not None:
@@ -127,6 +184,7 @@ def predict(img, model, transform, batch_size=32, patch_size=64, overlap=12, tri
         stream.synchronize()
         out = result.cpu().numpy().view(np.uint16)
         ctx.reset_stream()
+    del run
     if pbar is not None:
         pbar.close()
     return out
@@ -179,6 +237,7 @@ def load_model(path, device="cuda"):
     Accepts the current format ``{"model", "model_config", "transform"}`` and a bare legacy
     ``state_dict`` (transform then defaults to asinh).  Unlike the reference, ``N2V2UNet``
     checkpoints work (the reference forgets to import the class: inference.py:290-291)."""
+    _miopen_defaults()
     ckpt = torch.load(path, map_location=device)
     if isinstance(ckpt, dict) and "model" in ckpt:
         state_dict = ckpt["model"]

@@ -114,6 +114,29 @@ def test_unet_on_rocm_matches_reference_cpu_output():
     np.testing.assert_allclose(y, ref, atol=2e-3, rtol=1e-3)      # fp32 MIOpen vs fp32 CPU
 
 
+def test_ndhwc_shadow_matches_the_reference_cpu_output_and_leaves_the_model_alone():
+    """predict's default fast path (round 4): the forward passes run through an NDHWC copy of the model with
+    MIOpen's implicit-GEMM solvers.  Same fp32 arithmetic: the reference's CPU output at the existing
+    tolerance; the caller's module keeps its layout; fast=False calls the module as given and the two
+    volumes agree to the criterion of test_predict_with_unet_and_predict_patch."""
+    torch.manual_seed(0)
+    model = unet3d.UNet().cuda().eval()
+    shadow = inference._ndhwc_shadow(model)
+    w = next(p for p in shadow.parameters() if p.dim() == 5)
+    w0 = next(p for p in model.parameters() if p.dim() == 5)
+    assert w.is_contiguous(memory_format=torch.channels_last_3d) and w0.is_contiguous()
+    x = torch.randn(1, 1, 32, 32, 32, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        y = shadow(x.cuda()).cpu().numpy()
+    np.testing.assert_allclose(y, np.load(os.path.join(GOLD, "unet.npz"))["y"], atol=2e-3, rtol=1e-3)
+    tf = T.build_transform(TF_CFG)
+    vol = tiling_volume((64, 116, 116), seed=4)
+    a = inference.predict(vol, model, tf, batch_size=4, verbose=False).astype(np.int32)
+    b = inference.predict(vol, model, tf, batch_size=4, verbose=False, fast=False).astype(np.int32)
+    assert np.mean(np.abs(a - b) > 1) < 1e-3
+    assert w0.is_contiguous() and not model.training
+
+
 def test_n2v2_on_rocm_and_shape_contract():
     """N2V2UNet on ROCm against the reference's fp32 CPU output (fixture generated by importing
     the reference), and the shape contract of reference unet3d.py:574-590 at sizes 64 and 65."""
