@@ -241,6 +241,7 @@ def end_to_end_leg(ctx, vol, d_in, d_out, params, stages):
     exabm4d_denoise_chunked_u16_host (256^3 cores + 8-voxel halo, BASELINE config 4's chunk-local semantics:
     layers of chunks go up and come down while the neighbouring layer is in the kernels)."""
     import ctypes
+    from aind_exaspim_image_compression import _native
     lib = _native.lib()
     out = np.zeros(vol.shape, dtype=np.uint16)
     shape, n = vol.shape, vol.size
