@@ -383,7 +383,7 @@ def bm4dnet_reference_like(edge):
         "model = unet3d.UNet().cuda().eval()\n"
         "tf = T.build_transform({'kind': 'offset', 'base': {'kind': 'asinh', 'params': {'offset': 0.0, 'scale': 32.0}}, 'params': {'offset': bench.OFFSET}})\n"
         f"vol = bench.synth_u16(({edge},) * 3, seed=1000)\n"
-        "t0 = time.perf_counter(); inference.predict(vol[:64, :220, :428], model, tf, batch_size=32, verbose=False, fast=False); warm = time.perf_counter() - t0\n"
+        "t0 = time.perf_counter(); inference.predict(vol[:116, :220, :220], model, tf, batch_size=32, verbose=False, fast=False); warm = time.perf_counter() - t0\n"   # 2 x 4 x 4 patches: one full batch
         "t0 = time.perf_counter(); inference.predict(vol, model, tf, batch_size=32, verbose=False, fast=False); dt = time.perf_counter() - t0\n"
         "n = inference.count_patches(inference._ShapeOnly((1, 1) + vol.shape), 64, 12)\n"
         "print(json.dumps({'edge': vol.shape[0], 'patches': n, 'cold_start_seconds': round(warm, 3), 'seconds': round(dt, 3), 'unet_tflops': n * 109.639e9 / dt / 1e12}))\n"
