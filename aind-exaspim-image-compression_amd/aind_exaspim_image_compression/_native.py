@@ -127,7 +127,7 @@ SIGNATURES = {
     "exabm4d_i32_symbol_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
     "exabm4d_codec_chunk_bound": (_SZ, [_SZ, _I]),
     "exabm4d_codec_volume_bound": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
-    "exabm4d_codec_encode_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp, _SZ, c_vp, c_vp,
+    "exabm4d_codec_encode_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, _I, _I, c_vp, _SZ, c_vp, c_vp,
                                       c_vp]),
     "exabm4d_codec_decode_dev": (_I, [_CTX, c_vp, _SZ, c_vp, _I, _I, _I, _I, _I, _I, _I, c_vp]),
     "exabm4d_u16_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
@@ -499,13 +499,14 @@ class Context:
 
     # -- chunk entropy coder (row f-1) ------------------------------------------------------------
     def codec_encode(self, vol, typesize, shape, chunk, out=None, out_capacity=0, offsets=None,
-                     sizes=None, totals=True):
+                     sizes=None, totals=True, version=0):
         """Code every chunk of a device volume.  -> (sum of stream lengths, container bytes) when
-        `totals` (synchronises), else None."""
+        `totals` (synchronises), else None.  ``version``: EXAC format of THIS call (1 | 2; 0 = the
+        context's "codec_version" option)."""
         nz, ny, nx = shape
         tot = np.zeros(2, dtype=np.uint64)
         self._check(lib().exabm4d_codec_encode_dev(
-            self.handle, _ptr(vol), int(typesize), nz, ny, nx, int(chunk[0]), int(chunk[1]),
+            self.handle, _ptr(vol), int(typesize), int(version), nz, ny, nx, int(chunk[0]), int(chunk[1]),
             int(chunk[2]), _ptr(out), int(out_capacity), _ptr(offsets), _ptr(sizes),
             tot.ctypes.data_as(c_vp) if totals else None))
         return (int(tot[0]), int(tot[1])) if totals else None

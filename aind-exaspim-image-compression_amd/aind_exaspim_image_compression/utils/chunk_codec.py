@@ -156,12 +156,9 @@ class ExacCodec:
             if want_bytes:
                 cap = _native.codec_volume_bound(self.typesize, shape, chunk)
                 d_out = ctx.alloc(cap)
-            ctx.set_option("codec_version", self.version)
-            try:
-                _, container = ctx.codec_encode(d_vol, self.typesize, shape, chunk, out=d_out,
-                                                out_capacity=cap, offsets=d_off, sizes=d_sizes)
-            finally:
-                ctx.set_option("codec_version", 2)
+            # the format travels with the call (round 4): no shared context state is touched
+            _, container = ctx.codec_encode(d_vol, self.typesize, shape, chunk, out=d_out, out_capacity=cap,
+                                            offsets=d_off, sizes=d_sizes, version=self.version)
             sizes = d_sizes.download((nchunks,), np.uint32)
             offsets = d_off.download((nchunks + 1,), np.uint64)
             data = d_out.download((container,), np.uint8) if want_bytes else None

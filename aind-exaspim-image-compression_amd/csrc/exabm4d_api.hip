@@ -1246,12 +1246,13 @@ static int codec_aux(exabm4d_ctx* ctx, int nchunks, uint32_t*& sizes, unsigned l
     status = reinterpret_cast<uint32_t*>(base + a + b + 256);
     return EXABM4D_OK;
 }
-int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int nz, int ny, int nx,
+int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int version, int nz, int ny, int nx,
                              int cz, int cy, int cx, uint8_t* out, size_t out_capacity,
                              uint64_t* offsets_dev, uint32_t* sizes_dev, uint64_t* totals_host) {
     if (!ctx || !vol) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (version < 0 || version > 2) return fail(ctx, EXABM4D_ERR_INVALID, "codec: version must be 0 (context default), 1 or 2");
     CodecGeom g;
-    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g, ctx->codec_version))
+    if (make_codec_geom(typesize, nz, ny, nx, cz, cy, cx, g, version ? version : ctx->codec_version))
         return fail(ctx, EXABM4D_ERR_INVALID, "codec: typesize must be 2 or 4, sizes >= 1, chunk <= 2^28 elements");
     if (out && !offsets_dev) return fail(ctx, EXABM4D_ERR_INVALID, "codec: offsets_dev is required with out");
     if (out && out_capacity < codec_volume_bound(g))

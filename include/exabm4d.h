@@ -345,7 +345,9 @@ int exabm4d_i32_symbol_histogram_dev(exabm4d_ctx* ctx, const int32_t* idx, size_
  *   EXAC v1 (exabm4d_set_option("codec_version", 1)): byte shuffle + static order-0 rANS per byte
  *     plane (round 2's format; still decoded).
  * typesize 2 = uint16 volumes, 4 = int32 quantisation indices (exabm4d_dctq_forward_dev; coded
- * without prediction), mapped to unsigned by (v << 1) ^ (v >> 31).
+ * without prediction), mapped to unsigned by (v << 1) ^ (v >> 31).  version = 1 | 2 selects the format per
+ * CALL (round 4: two codecs of different versions may share a context from two threads); 0 = the context's
+ * "codec_version" option (default 2).
  *
  * One call codes every chunk of a volume.  out (device, may be NULL: sizes only) receives the chunk
  * streams back to back, each starting at a multiple of 16 bytes (padding zeroed); out_capacity must
@@ -356,7 +358,7 @@ int exabm4d_i32_symbol_histogram_dev(exabm4d_ctx* ctx, const int32_t* idx, size_
  * lengths, container bytes }.  Chunks are numbered in (z, y, x) raster order. */
 size_t exabm4d_codec_chunk_bound(size_t n_elems, int typesize);
 size_t exabm4d_codec_volume_bound(int typesize, int nz, int ny, int nx, int cz, int cy, int cx);
-int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int nz, int ny, int nx,
+int exabm4d_codec_encode_dev(exabm4d_ctx* ctx, const void* vol, int typesize, int version, int nz, int ny, int nx,
                              int cz, int cy, int cx, uint8_t* out, size_t out_capacity,
                              uint64_t* offsets_dev, uint32_t* sizes_dev, uint64_t* totals_host);
 /* Inverse: in (in_bytes bytes on the device) + offsets_dev as produced above (or assembled by a host
