@@ -125,6 +125,11 @@ SIGNATURES = {
     "exabm4d_dctq_forward_dev": (_I, [_CTX, c_vp, _I, _I, _I, ctypes.c_float, c_vp]),
     "exabm4d_dctq_inverse_dev": (_I, [_CTX, c_vp, _I, _I, _I, ctypes.c_float, c_vp]),
     "exabm4d_i32_symbol_histogram_dev": (_I, [_CTX, c_vp, _SZ, c_vp]),
+    "exabm4d_comm_unique_id": (_I, [c_vp]),
+    "exabm4d_comm_create": (_I, [_CTX, _I, _I, c_vp, ctypes.POINTER(c_vp)]),
+    "exabm4d_comm_destroy": (_I, [c_vp]),
+    "exabm4d_halo_exchange_dev": (_I, [_CTX, c_vp, _I, c_vp, c_vp, _SZ, _I, c_vp, c_vp, _SZ]),
+    "exabm4d_comm_max_f64_host": (_I, [_CTX, c_vp, ctypes.POINTER(ctypes.c_double)]),
     "exabm4d_codec_chunk_bound": (_SZ, [_SZ, _I]),
     "exabm4d_codec_volume_bound": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
     "exabm4d_codec_encode_dev": (_I, [_CTX, c_vp, _I, _I, _I, _I, _I, _I, _I, _I, c_vp, _SZ, c_vp, c_vp,
@@ -568,6 +573,50 @@ class Context:
         if self.handle and os.getpid() == self.pid:
             lib().exabm4d_destroy(self.handle)
         self.handle = None
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 draws them; every rank passes them to ``Comm``)."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    rc = lib().exabm4d_comm_unique_id(buf)
+    if rc:
+        raise NativeError(lib().exabm4d_last_error(None).decode())
+    return bytes(buf)
+
+
+class Comm:
+    """An RCCL communicator bound to a context's device (exabm4d_comm_*): the halo exchange of the sharded
+    modes without torch.distributed.  Creation is collective over the ranks."""
+
+    def __init__(self, ctx, nranks, rank, unique_id):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % COMM_ID_BYTES)
+        self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+        h = c_vp()
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        ctx._check(lib().exabm4d_comm_create(ctx.handle, self.nranks, self.rank, buf, ctypes.byref(h)))
+        self.handle = h
+
+    def halo_exchange(self, lo_peer, send_lo, recv_lo, bytes_lo, hi_peer, send_hi, recv_hi, bytes_hi):
+        """ncclGroupStart; send / recv with each neighbour; ncclGroupEnd -- on the context's stream, device
+        pointers (ints, DeviceBuffers or tensors), a peer of -1 skips that side."""
+        self.ctx._check(lib().exabm4d_halo_exchange_dev(
+            self.ctx.handle, self.handle, int(lo_peer), _ptr(send_lo), _ptr(recv_lo), int(bytes_lo),
+            int(hi_peer), _ptr(send_hi), _ptr(recv_hi), int(bytes_hi)))
+
+    def max(self, value):
+        """max over the ranks of ``value`` (a float); synchronises the context's stream: barrier + MAX."""
+        v = ctypes.c_double(float(value))
+        self.ctx._check(lib().exabm4d_comm_max_f64_host(self.ctx.handle, self.handle, ctypes.byref(v)))
+        return float(v.value)
+
+    def close(self):
+        if self.handle:
+            lib().exabm4d_comm_destroy(self.handle)
+            self.handle = None
 
 
 _contexts = {}

@@ -166,8 +166,10 @@ def global_data_exp(noisy, dist=None, group=None):
     slab mode adds to its halo exchange).  ``noisy``: this rank's planes as a torch tensor."""
     import torch
     bits = int(noisy.detach().abs().max().view(torch.int32).item()) if noisy.numel() else 0
-    e = torch.tensor([(bits >> 23) - 126], dtype=torch.int32, device=noisy.device)
+    e = torch.tensor([(bits >> 23) - 126], dtype=torch.int32)
     if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) != "gloo":          # RCCL reduces device tensors, gloo host tensors
+            e = e.to(noisy.device)
         dist.all_reduce(e, op=dist.ReduceOp.MAX, group=group)
     return int(e.item())
 
@@ -323,3 +325,128 @@ class ChunkedSlabDenoiser:
             stream.synchronize()
             ctx.reset_stream()
         return out
+
+
+# ---- the same two modes without torch: RCCL behind the C-ABI (round 4) ---------------------------------------
+# north_star: "PyTorch-ROCm used only for the bm4dnet stage ... RCCL over xGMI only for halo exchange".  The
+# classes above keep their slabs in torch tensors and exchange through torch.distributed (what the gloo tests
+# and the single-GPU rehearsals run); the functions below need neither: DeviceBuffers, the context's stream,
+# and exabm4d_halo_exchange_dev (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, csrc/comm_rccl.hip).
+def halo_messages(plan, plane_bytes, what="basic"):
+    """Byte offsets inside a padded slab buffer [p1 - p0 planes] of the four messages of one exchange:
+    -> ((lo_peer, send_lo_off, recv_lo_off, bytes_lo), (hi_peer, send_hi_off, recv_hi_off, bytes_hi)); a peer of
+    -1 = no neighbour on that side.  A rank sends the outer ``halo`` planes it OWNS and receives its
+    neighbour's into its halo region; the planes of a slab are contiguous, so these are plain ranges."""
+    core = plan.core
+    n_own = plan.z1 - plan.z0
+    h = min(plan.halo, n_own)
+    lo = (-1, 0, 0, 0)
+    hi = (-1, 0, 0, 0)
+    if plan.rank > 0:
+        lo = (plan.rank - 1, core.start * plane_bytes, 0, plan.lo * plane_bytes)
+        if plan.lo != h:
+            raise ValueError("slab thinner than its neighbour's halo")
+    if plan.rank < plan.world - 1:
+        hi = (plan.rank + 1, (core.stop - h) * plane_bytes, core.stop * plane_bytes, plan.hi * plane_bytes)
+        if plan.hi != h:
+            raise ValueError("slab thinner than its neighbour's halo")
+    return lo, hi
+
+
+def exchange_halo_native(comm, buf, plan, plane_bytes):
+    """One halo exchange of the padded slab ``buf`` (DeviceBuffer / device pointer) on the context's stream."""
+    if plan.world == 1:
+        return
+    from aind_exaspim_image_compression import _native
+    base = _native._ptr(buf)
+    (lp, ls, lr, lb), (hp, hs, hr, hb) = halo_messages(plan, plane_bytes)
+    comm.halo_exchange(lp, base + ls, base + lr, lb, hp, base + hs, base + hr, hb)
+
+
+def rendezvous_comm(ctx, rank, world, tag=None, timeout=180.0):
+    """A ``_native.Comm`` over all ranks of a single-node job, without torch: rank 0 draws the RCCL unique id
+    and publishes it in a file the other ranks poll for (same node, so the temp directory is shared; the name
+    carries the launcher's pid and MASTER_PORT / TORCHELASTIC_RUN_ID, so that two jobs do not meet)."""
+    import os
+    import tempfile
+    import time
+    from aind_exaspim_image_compression import _native
+    if tag is None:
+        tag = "%s-%s-%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("MASTER_PORT", "0"),
+                            os.getppid())
+    path = os.path.join(tempfile.gettempdir(), f"exabm4d-comm-{os.getuid()}-{tag}.id")
+    if rank == 0:
+        uid = _native.comm_unique_id()
+        fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+    else:
+        t0 = time.time()
+        uid = b""
+        while len(uid) != _native.COMM_ID_BYTES:
+            try:
+                with open(path, "rb") as f:
+                    uid = f.read()
+            except FileNotFoundError:
+                pass
+            if len(uid) != _native.COMM_ID_BYTES:
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"rank {rank}: no RCCL id from rank 0 in {path}")
+                time.sleep(0.02)
+    comm = _native.Comm(ctx, world, rank, uid)          # collective: returns once every rank has the id
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return comm
+
+
+def denoise_slab_u16_native(ctx, comm, d_raw, plan, shape, sigma, offset, params=None):
+    """The exact slab mode of ``denoise_slab_u16`` on DeviceBuffers: ``d_raw`` holds this rank's padded slab of
+    uint16 counts ([p1 - p0, ny, nx]); returns a DeviceBuffer with the padded slab's uint16 result (the owned
+    planes are ``plan.core``).  Stage 1 on the padded slab, the basic estimate's halo from the neighbours
+    through ``comm`` (fp32 planes as bytes), stage 2, the uint16 cast -- everything on the context's stream,
+    no host synchronisation inside."""
+    from aind_exaspim_image_compression import _native
+    p = params or _native.default_params()
+    shape = tuple(int(s) for s in shape)
+    n = int(shape[0]) * shape[1] * shape[2]
+    g = [len(_native.grid_positions(m)) for m in shape]
+    d_noisy, d_basic = ctx.alloc(4 * n), ctx.alloc(4 * n)
+    d_num, d_den = ctx.alloc(4 * n), ctx.alloc(4 * n)
+    d_keys = ctx.alloc(g[0] * g[1] * g[2] * 64)
+    d_out = ctx.alloc(2 * n)
+    try:
+        ctx.counts_from_u16(d_raw, d_noisy, n, float(offset))
+        if offset_exact_in_fp32(offset):
+            ctx.blockmatch_u16(d_raw, shape, sigma, p.c_match_ht, d_keys, p)
+        else:
+            ctx.blockmatch(d_noisy, shape, sigma, p.c_match_ht, d_keys, p)
+        ctx.stage(d_noisy, None, d_keys, shape, sigma, d_num, d_den, p, data_exp=_native.DATA_EXP_U16)
+        ctx.normalize(d_num, d_den, d_basic, n)
+        exchange_halo_native(comm, d_basic, plan, 4 * shape[1] * shape[2])
+        ctx.blockmatch(d_basic, shape, sigma, p.c_match_wie, d_keys, p)
+        ctx.stage(d_noisy, d_basic, d_keys, shape, sigma, d_num, d_den, p, data_exp=_native.DATA_EXP_U16)
+        ctx.normalize_u16(d_num, d_den, d_out, n, float(offset))
+        return d_out
+    finally:
+        ctx.sync()
+        for b in (d_noisy, d_basic, d_num, d_den, d_keys):
+            b.free()
+
+
+def denoise_chunked_slab_native(ctx, comm, d_raw, plan, shape, sigma, offset, chunk=256, halo=8, params=None):
+    """Chunk-local mode (BASELINE config 4) of this rank's slab on DeviceBuffers: the neighbours' ``halo`` raw
+    planes arrive through ``comm`` (uint16 planes as bytes), then one batched
+    ``exabm4d_denoise_chunked_u16_dev`` call over the owned chunk layers.  Returns a DeviceBuffer with the
+    owned planes.  (The torch path overlaps the exchange with the interior layers; here it is simply ordered
+    on the one stream in front of the kernels: 8 planes are 0.5 % of the data a rank reads.)"""
+    shape = tuple(int(s) for s in shape)
+    exchange_halo_native(comm, d_raw, plan, 2 * shape[1] * shape[2])
+    core = plan.core
+    d_out = ctx.alloc(2 * (core.stop - core.start) * shape[1] * shape[2])
+    ctx.denoise_chunked_u16(d_raw, d_out, shape, float(sigma), float(offset), chunk=int(chunk), halo=int(halo),
+                            core=(core.start, core.stop), params=params)
+    return d_out

@@ -234,6 +234,11 @@ std::vector<ChunkRun> chunk_runs(int n, int c0, int c1, int chunk, int halo) {
 
 extern "C" {
 
+// for the other translation units of the library (comm_rccl.hip); not part of the ABI
+int exabm4d_internal_fail(exabm4d_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
+hipStream_t exabm4d_internal_stream(exabm4d_ctx* ctx) { return ctx->stream; }
+int exabm4d_internal_device(exabm4d_ctx* ctx) { return ctx->device; }
+
 int exabm4d_version(void) { return EXABM4D_VERSION; }
 
 const char* exabm4d_last_error(const exabm4d_ctx* ctx) {

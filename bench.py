@@ -462,7 +462,7 @@ def torch_encode_legs(ctx, own, dev):
     return encode, sz16
 
 
-def run_slabs(args, rank, local_rank, world, dist):
+def run_slabs(args, rank, local_rank, world, dist, group=None):
     """N ranks, ONE volume of N*size planes: every rank holds its z-slab plus a 24-plane halo,
     runs stage 1 (uint16 matching), exchanges the basic estimate's halo with its slab neighbours
     (RCCL isend / irecv; 24 planes = 100 MB per neighbour at 1024^2, ~2 ms over xGMI against a
@@ -484,7 +484,7 @@ def run_slabs(args, rank, local_rank, world, dist):
     encode, sz16 = torch_encode_legs(ctx, own, dev)
 
     def step():
-        out = denoise_slab_u16(raw, plan, OFFSET, den, dist=dist).contiguous()
+        out = denoise_slab_u16(raw, plan, OFFSET, den, dist=dist, group=group).contiguous()
         if not args.no_encode:
             encode(out)
         return out
@@ -492,7 +492,7 @@ def run_slabs(args, rank, local_rank, world, dist):
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=group)
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -504,9 +504,8 @@ def run_slabs(args, rank, local_rank, world, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if group is None else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
     if rank == 0:
         resid = (out[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float() - \
@@ -532,7 +531,7 @@ def run_slabs(args, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
-def run_chunks(args, rank, local_rank, world, dist):
+def run_chunks(args, rank, local_rank, world, dist, group=None):
     """BASELINE config 4: N ranks, ONE volume of N*size planes in chunk-local mode -- 256^3 cores
     with an 8-voxel halo, every padded chunk denoised in isolation.  A rank owns whole layers of
     chunks; the only exchange is the raw uint16 input halo (8 planes to each slab neighbour, RCCL
@@ -558,7 +557,7 @@ def run_chunks(args, rank, local_rank, world, dist):
 
     def step():
         raw[plan.core] = own                   # only the owned planes are known before the exchange
-        out = denoise_chunked_slab(raw, plan, den.run, chunk=chunk, dist=dist).contiguous()
+        out = denoise_chunked_slab(raw, plan, den.run, chunk=chunk, dist=dist, group=group).contiguous()
         if not args.no_encode:
             encode(out)
         return out
@@ -566,7 +565,7 @@ def run_chunks(args, rank, local_rank, world, dist):
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=group)
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -578,9 +577,8 @@ def run_chunks(args, rank, local_rank, world, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if group is None else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
     if rank == 0:
         resid = (out[::8, ::8, ::8].to(torch.int32) & 0xFFFF).float() - \
@@ -605,6 +603,112 @@ def run_chunks(args, rank, local_rank, world, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def native_encode_legs(ctx, own):
+    """torch_encode_legs on DeviceBuffers (the torch-free sharded modes)."""
+    from aind_exaspim_image_compression import _native
+    nchunks = int(np.prod([-(-m // c) for m, c in zip(own, CHUNK)]))
+    cap16 = _native.codec_volume_bound(2, own, CHUNK)
+    enc16, off16, sz16 = ctx.alloc(cap16), ctx.alloc(8 * (nchunks + 1)), ctx.alloc(4 * nchunks)
+    nblk = int(np.prod([-(-m // 8) for m in own]))
+    idx_shape, idx_chunk = (nblk, 8, 64), (512, 8, 64)
+    nchunks_i = -(-nblk // 512)
+    cap32 = _native.codec_volume_bound(4, idx_shape, idx_chunk)
+    idx = ctx.alloc(4 * nblk * 512)
+    enc32, off32, sz32 = ctx.alloc(cap32), ctx.alloc(8 * (nchunks_i + 1)), ctx.alloc(4 * nchunks_i)
+
+    def encode(out_ptr):
+        ctx.codec_encode(out_ptr, 2, own, CHUNK, out=enc16, out_capacity=cap16, offsets=off16, sizes=sz16, totals=False)
+        ctx.dctq_forward(out_ptr, own, Q_STEP, idx)
+        ctx.codec_encode(idx, 4, idx_shape, idx_chunk, out=enc32, out_capacity=cap32, offsets=off32, sizes=sz32,
+                         totals=False)
+
+    return encode, lambda: sz16.download((nchunks,), np.uint32)
+
+
+def run_sharded_native(args, rank, local_rank, world):
+    """--mode slabs | chunks with --comm native: the same two sharded modes WITHOUT torch -- DeviceBuffers, the
+    context's stream, the halo exchange through exabm4d_halo_exchange_dev (ncclGroupStart / ncclSend / ncclRecv /
+    ncclGroupEnd behind the C-ABI, csrc/comm_rccl.hip), the timed region bracketed by exabm4d_comm_max_f64_host
+    (an RCCL all-reduce + stream synchronisation: barrier and MAX in one).  north_star: "PyTorch-ROCm used only
+    for the bm4dnet stage ... RCCL over xGMI only for halo exchange"."""
+    assert "torch" not in sys.modules, "the native sharded modes must not import torch"
+    from aind_exaspim_image_compression import _native
+    from aind_exaspim_image_compression.distributed import (denoise_chunked_slab_native, denoise_slab_u16_native,
+                                                            plan_chunk_slabs, plan_slabs, rendezvous_comm)
+    ctx = _native.context(local_rank)
+    apply_env_options(ctx)
+    comm = rendezvous_comm(ctx, rank, world)
+    chunked = args.mode == "chunks"
+    chunk, halo = args.chunk, 8
+    pz, py, px = (args.size,) * 3 if not (chunked and args.shape) else tuple(int(v) for v in args.shape.split(","))
+    shape = (pz * world, py, px)
+    plan = plan_chunk_slabs(shape[0], world, rank, chunk=chunk, halo=halo) if chunked else plan_slabs(shape[0], world, rank)
+    pshape = (plan.p1 - plan.p0, py, px)
+    plane = py * px
+    core = plan.core
+    own_shape = (plan.z1 - plan.z0, py, px)
+    # chunks: only the owned planes are known before the exchange; slabs: every rank reads its padded range
+    host = synth_u16(shape, seed=3000 if chunked else 2000, z_range=(plan.z0, plan.z1) if chunked else (plan.p0, plan.p1))
+    d_raw = ctx.alloc(2 * pshape[0] * plane).zero()
+    own_host = host if chunked else host[core]
+    if chunked:
+        ctx._check(_native.lib().exabm4d_memcpy_h2d(ctx.handle, d_raw.ptr + 2 * core.start * plane, host.ctypes.data,
+                                                    host.nbytes))
+    else:
+        d_raw.upload(host)
+    encode, sizes16 = native_encode_legs(ctx, own_shape)
+    last = [None]
+
+    def step():
+        if last[0] is not None:
+            last[0].free()
+        if chunked:
+            out = denoise_chunked_slab_native(ctx, comm, d_raw, plan, pshape, SIGMA, OFFSET, chunk=chunk, halo=halo)
+            own_ptr = out.ptr
+        else:
+            out = denoise_slab_u16_native(ctx, comm, d_raw, plan, pshape, SIGMA, OFFSET)
+            own_ptr = out.ptr + 2 * core.start * plane
+        if not args.no_encode:
+            encode(own_ptr)
+        last[0] = out
+        return own_ptr
+
+    for _ in range(args.warmup):
+        step()
+    comm.max(0.0)                                         # barrier
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        own_ptr = step()
+    ctx.sync()
+    elapsed = comm.max(time.perf_counter() - t0)          # ... and the slowest rank's time
+    if rank == 0:
+        out = np.empty(own_shape, np.uint16)
+        ctx._check(_native.lib().exabm4d_memcpy_d2h(ctx.handle, out.ctypes.data, own_ptr, out.nbytes))
+        resid = out[::8, ::8, ::8].astype(np.float32) - own_host[::8, ::8, ::8].astype(np.float32)
+        emit(json.dumps({
+            "metric": "denoised+encoded voxels/s on 1024^3 uint16",
+            "value": world * pz * py * px * args.steps / elapsed,
+            "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"{shape[0]}x{py}x{px} uint16 volume, chunk-local two-stage BM4D: {chunk}^3 cores + "
+                                    f"{halo}-voxel halo, {world} z-slab(s) of whole chunk layers" if chunked else
+                                    f"{shape[0]}x{py}x{px} uint16 volume in {world} z-slab(s), two-stage BM4D, 24-plane "
+                                    "halo exchange of the basic estimate"),
+                       "volume": list(shape), "stages": 2,
+                       "encode": "none" if args.no_encode else
+                       f"lossless EXAC + 8^3 DCT q={Q_STEP:g} + EXAC of the indices, on the own planes",
+                       "sharding": "z-slabs; halo exchange = exabm4d_halo_exchange_dev (RCCL send / recv behind the "
+                                   "C-ABI), rendezvous and barrier without torch",
+                       "comm": "native"},
+            "residual_std": float(resid.std()),
+            "rank0_lossless_cratio": None if args.no_encode else
+            round(2.0 * float(np.prod(own_shape)) / float(sizes16().astype(np.uint64).sum()), 2),
+        }))
+    comm.max(0.0)
+    comm.close()
 
 
 ENV_OPTIONS = {                      # A/B switches of tools/dbg: environment variable -> exabm4d_set_option name
@@ -700,6 +804,9 @@ def main():
                          "estimate between the two stages (distributed.py); 'chunks' = BASELINE "
                          "config 4: the same volume in chunk-local mode (--chunk^3 cores + 8-voxel "
                          "halo), raw-input halo exchange only")
+    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
+                    help="--mode slabs | chunks: 'torch' = torch.distributed point-to-point (RCCL under the nccl "
+                         "backend); 'native' = exabm4d_halo_exchange_dev, rendezvous and barrier without importing torch")
     ap.add_argument("--no-encode", action="store_true",
                     help="time the denoiser alone (the metric's step includes the encode legs)")
     ap.add_argument("--end-to-end", type=int, default=1,
@@ -727,49 +834,57 @@ def main():
     if os.environ.get("BENCH_FAIL_RANK") == str(rank) and world > 1:
         raise SystemExit(3)                     # tests: a rank that dies must fail the launcher
 
+    if args.comm == "native" and args.mode in ("slabs", "chunks"):
+        if os.environ.get("BENCH_REHEARSAL"):
+            local_rank = 0                      # a one-GPU box can rehearse world = 1 only (RCCL: one rank per device)
+        if world > 1:
+            quiet_stdout()
+        return run_sharded_native(args, rank, local_rank, world)
+
     dist = None
     torch = None
+    group = None
     # BENCH_REHEARSAL=1: rehearse the multi-rank control flow on a box with ONE GPU -- gloo
     # rendezvous, every rank on device 0 (never the measured configuration).
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
     if world > 1:
         quiet_stdout()
+        import datetime
         import torch
         import torch.distributed as dist
+        # The ranks ALWAYS meet over gloo first; RCCL comes up as a second group and the ranks AGREE (one MIN
+        # all-reduce over gloo) whether it did.  A rank that alone falls back would leave the others inside an
+        # RCCL collective until its timeout.
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         if rehearsal:
             local_rank = 0
-            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             if os.environ.get("BENCH_REHEARSAL") == "2":     # tests: the RCCL rendezvous fails, on a one-GPU box
                 local_rank = 0
             torch.cuda.set_device(local_rank)
+            ok, why = 1, ""
             try:
-                import datetime
                 if os.environ.get("BENCH_REHEARSAL") == "2":
                     raise RuntimeError("rehearsal: RCCL forced down")
-                dist.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank),
-                                        timeout=datetime.timedelta(seconds=180))
+                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
                 probe = torch.ones(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(probe)                       # builds the RCCL communicator now, not inside the timed region
+                dist.all_reduce(probe, group=group)          # builds the RCCL communicator now, not inside the timed region
                 torch.cuda.synchronize()
                 assert int(probe.item()) == world
             except Exception as exc:                         # noqa: BLE001
-                # The default mode has no data-path collective (one independent volume per rank): the
-                # rendezvous only brackets the timed region.  If RCCL cannot come up on this node, the ranks
-                # meet over gloo instead (same barrier + MAX reduction on CPU tensors) and the line says so;
-                # the slab / chunk modes exchange device planes and fail loudly.
+                ok, why = 0, repr(exc)
+                print(f"[bench] rank {rank}: RCCL did not come up ({exc!r})", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # over gloo: every rank learns the common answer
+            if int(flag.item()) == 0:
+                # The default mode has no data-path collective (one independent volume per rank): the rendezvous
+                # only brackets the timed region, gloo does that as well and the line says so.  The slab / chunk
+                # modes exchange device planes: they stop, all ranks together, with a non-zero status.
+                group = None
                 if args.mode != "volumes":
-                    raise
-                print(f"[bench] rank {rank}: RCCL rendezvous failed ({exc!r}); falling back to gloo for the barrier",
-                      file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                except Exception:                            # noqa: BLE001
-                    pass
-                os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-                RENDEZVOUS_NOTE.append("gloo (RCCL did not come up: %s)" % type(exc).__name__)
+                    raise SystemExit(f"rank {rank}: RCCL is down on at least one rank ({why or 'another rank'}); "
+                                     f"--mode {args.mode} needs it")
+                RENDEZVOUS_NOTE.append("gloo (RCCL did not come up on every rank)")
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     # (import order of torch and libexabm4d.so is free: _native.lib() settles which HIP runtime the
@@ -777,9 +892,9 @@ def main():
     from aind_exaspim_image_compression import _native
 
     if args.mode == "slabs":
-        return run_slabs(args, rank, local_rank, world, dist)
+        return run_slabs(args, rank, local_rank, world, dist, group)
     if args.mode == "chunks":
-        return run_chunks(args, rank, local_rank, world, dist)
+        return run_chunks(args, rank, local_rank, world, dist, group)
 
     ctx = _native.context(local_rank)
     shape = (args.size,) * 3
@@ -793,7 +908,7 @@ def main():
         ctx.sync()
         if dist is not None:
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(group=group)
             torch.cuda.synchronize()
 
     # encode legs: packed streams, offsets and sizes stay in HBM
@@ -839,9 +954,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if group is None else f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(t.item())
 
     # size-independent sanity property at full size: output is a denoised version of the input

@@ -276,6 +276,31 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
                              int batch, float sigma, const exabm4d_params* p, int stages,
                              float clip_lo, float clip_hi);
 
+/* ---- multi-GPU: halo exchange over RCCL (north_star "RCCL over xGMI only for halo
+ * exchange at chunk borders") ------------------------------------------------------------------------------
+ * One process per GPU.  librccl.so is dlopen()ed on first use (EXABM4D_RCCL_LIB names another copy, e.g.
+ * the one a PyTorch in the same process ships); a host without RCCL gets EXABM4D_ERR_UNSUPPORTED.
+ * Rank 0 draws the id (ncclGetUniqueId) and the host layer hands it to the other ranks (distributed.py does it
+ * over MASTER_ADDR / MASTER_PORT without torch); exabm4d_comm_create is collective over the ranks
+ * (ncclCommInitRank on the context's device). */
+#define EXABM4D_COMM_ID_BYTES 128
+typedef struct exabm4d_comm exabm4d_comm;
+int exabm4d_comm_unique_id(uint8_t id[EXABM4D_COMM_ID_BYTES]);
+int exabm4d_comm_create(exabm4d_ctx* ctx, int nranks, int rank, const uint8_t id[EXABM4D_COMM_ID_BYTES],
+                        exabm4d_comm** out);
+int exabm4d_comm_destroy(exabm4d_comm* comm);
+/* The exchange of SURVEY.md 8e on the context's stream, no host synchronisation: ncclGroupStart; send
+ * `send_lo` to rank lo_peer and receive `recv_lo` from it (bytes_lo each way); the same with hi_peer;
+ * ncclGroupEnd.  A peer of -1 (or 0 bytes) skips that side (the first and the last slab).  All pointers are
+ * device pointers; the planes of a z-slab are contiguous, so callers pass addresses inside their slab
+ * buffers.  Replaces the torch.distributed isend / irecv pairs of distributed.HaloExchange. */
+int exabm4d_halo_exchange_dev(exabm4d_ctx* ctx, exabm4d_comm* comm, int lo_peer, const void* send_lo, void* recv_lo,
+                              size_t bytes_lo, int hi_peer, const void* send_hi, void* recv_hi, size_t bytes_hi);
+
+/* *value = max over the ranks of *value (ncclAllReduce of one double on the context's stream, then a
+ * synchronisation): the barrier + MAX that brackets a timed region (bench.py) without torch.distributed. */
+int exabm4d_comm_max_f64_host(exabm4d_ctx* ctx, exabm4d_comm* comm, double* value);
+
 /* ---- intensity transforms (a-D, a-E) ------------------------------------------------------- */
 int exabm4d_transform_forward_u16_dev(exabm4d_ctx* ctx, const exabm4d_transform* t,
                                       const uint16_t* in, float* out, size_t n);

@@ -147,3 +147,36 @@ def test_two_rank_slabs_equal_whole_volume(oracle, tmp_path):
         got[z0:z1] = np.load(tmp_path / f"slab{r}.npy")
     # exact halo (24) and integer aggregation sums (round 4): the sharded result IS the whole-volume result
     np.testing.assert_array_equal(got, want)
+
+
+def test_native_halo_messages_fill_every_halo_from_its_owner():
+    """distributed.halo_messages (the byte ranges exabm4d_halo_exchange_dev moves): emulate the exchange of
+    every rank's padded slab on the host -- whatever a rank receives must be exactly the planes its neighbour
+    owns, for several worlds, halos and ragged plane counts; sizes of the two sides of a message agree."""
+    from aind_exaspim_image_compression.distributed import halo_messages, plan_slabs
+    rng = np.random.default_rng(0)
+    for nz, world, halo, align in ((96, 2, 24, 4), (200, 3, 24, 4), (1024, 8, 24, 4), (96, 4, 8, 16), (130, 3, 8, 4)):
+        plane = 7                                                   # bytes per plane
+        vol = rng.integers(0, 256, (nz, plane)).astype(np.uint8)
+        plans = [plan_slabs(nz, world, r, halo=halo, align=align, halo_step=4 if halo % 4 == 0 else 1) for r in range(world)]
+        slabs = []
+        for p in plans:
+            s = np.full((p.p1 - p.p0, plane), 0xEE, np.uint8)
+            s[p.core] = vol[p.z0:p.z1]                               # only the owned planes are known
+            slabs.append(s.reshape(-1))
+        msgs = [halo_messages(p, plane) for p in plans]
+        for r, (lo, hi) in enumerate(msgs):
+            if r > 0:
+                assert lo[0] == r - 1 and lo[3] == msgs[r - 1][1][3]     # my lower message = my neighbour's upper one
+            if r < world - 1:
+                assert hi[0] == r + 1
+        new = [s.copy() for s in slabs]
+        for r, (lo, hi) in enumerate(msgs):
+            if lo[0] >= 0:      # what I receive from below is what rank r-1 sends upwards
+                src = msgs[r - 1][1]
+                new[r][lo[2]:lo[2] + lo[3]] = slabs[r - 1][src[1]:src[1] + src[3]]
+            if hi[0] >= 0:
+                src = msgs[r + 1][0]
+                new[r][hi[2]:hi[2] + hi[3]] = slabs[r + 1][src[1]:src[1] + src[3]]
+        for p, s in zip(plans, new):
+            np.testing.assert_array_equal(s.reshape(-1, plane), vol[p.p0:p.p1])
