@@ -75,8 +75,9 @@ __global__ __launch_bounds__(CQ_WAVES * 64) void dctq_inverse_kernel(
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = mk2((float)ia[u * 64] * q, (float)ib[u * 64] * q);
         pair_inv(T, tb, hi, lo, v);
-        // layout L1: lane = (z, x), registers = y; only voxels inside the volume are written
-        const int z = 8 * bz + hi, xa = 8 * bx0 + lo, xb = 8 * bx1 + lo;
+        // layout L1 up to tr_x (dct_pairs.h): lane = (z, x = tr_x(hi, lo)), registers = y; only voxels inside
+        // the volume are written
+        const int z = 8 * bz + hi, xa = 8 * bx0 + tr_x<false>(hi, lo), xb = 8 * bx1 + tr_x<false>(hi, lo);
 #pragma unroll
         for (int y = 0; y < 8; y++) {
             const int yy = 8 * by + y;

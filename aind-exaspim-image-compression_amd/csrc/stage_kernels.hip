@@ -165,9 +165,6 @@ struct TileGeom {
 #ifndef EXABM4D_HT_NPL
 #define EXABM4D_HT_NPL 18
 #endif
-#ifndef EXABM4D_HT_HALF_TBUF
-#define EXABM4D_HT_HALF_TBUF 0                 // 1: half-size transpose buffers (dct_pairs.h) -> more ring planes
-#endif
 #ifndef EXABM4D_WIE_NW
 #define EXABM4D_WIE_NW 8
 #endif
@@ -191,10 +188,9 @@ struct PairMap {
     static __device__ __forceinline__ int partner(int w) { return SAME ? w ^ 4 : w ^ 1; }
     static __device__ __forceinline__ int pair(int w) { return SAME ? (w & 3) : w >> 1; }
 };
-template <int NW_, int TY_, int TX_, int NPL_, bool HALFTB_ = false>
+template <int NW_, int TY_, int TX_, int NPL_>
 struct HalfGeom {
-    static constexpr bool HALFTB = HALFTB_;             // one pair component at a time through a float buffer
-    static constexpr int TBW = HALFTB_ ? TBUF1 : 2 * TBUF;   // floats of LDS per wave buffer
+    static constexpr int TBW = 2 * TBUF;                // floats of LDS per wave buffer
     static constexpr int NW = NW_;                      // waves: pair p = wave >> 1, half h = wave & 1 (the
                                                         // waves of a pair sit on different SIMDs)
     static constexpr int TY = TY_, TX = TX_;            // grid points per tile in y and x
@@ -208,7 +204,7 @@ struct HalfGeom {
     static_assert(LDS_FLOATS * sizeof(float) <= 160 * 1024, "ring + transpose buffers exceed the CU's LDS");
 };
 template <bool WIENER>
-struct HalfCfg : HalfGeom<EXABM4D_HT_NW, EXABM4D_HT_TY, EXABM4D_HT_TX, EXABM4D_HT_NPL, EXABM4D_HT_HALF_TBUF != 0> {};
+struct HalfCfg : HalfGeom<EXABM4D_HT_NW, EXABM4D_HT_TY, EXABM4D_HT_TX, EXABM4D_HT_NPL> {};
 template <>
 struct HalfCfg<true> : HalfGeom<EXABM4D_WIE_NW, EXABM4D_WIE_TY, EXABM4D_WIE_TX, EXABM4D_WIE_NPL> {};
 constexpr int HNCNT = 8;                      // per-layer report counters
@@ -457,6 +453,7 @@ __device__ __forceinline__ bool process_half_group(
                                                                  //  and waits 1.5 % of its time at the gate)
     constexpr int NP = WIENER ? 8 : 4;         // f2 values per lane swapped with the partner
     const int hi = lane >> 3, lo = lane & 7;
+    const int xl = tr_x<WIENER>(hi, lo);               // the block column this lane holds after the inverse transforms (dct_pairs.h)
     STAMP(t0);
     using PM = PairMap<WIENER && EXABM4D_WIE_PAIR_SAME_SIMD && HalfCfg<WIENER>::NW == 8>;
     const int half = PM::half(wave), partner = PM::partner(wave);
@@ -536,7 +533,7 @@ __device__ __forceinline__ bool process_half_group(
                     gather8v(noisy_r, corner_of(kb + kl + 6), voff, c);
                     gather8v(noisy_r, corner_of(kb + kl + 7), voff, d);
                 }
-                pair_fwd_x2<C::HALFTB>(T, tb, hi, lo, v2, w2);
+                pair_fwd_x2<WIENER>(T, tb, hi, lo, v2, w2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -556,7 +553,7 @@ __device__ __forceinline__ bool process_half_group(
                     gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
                     gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
                 }
-                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
+                pair_fwd<WIENER>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
                 if constexpr (KH > 1) {
@@ -574,7 +571,7 @@ __device__ __forceinline__ bool process_half_group(
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
-            pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
+            pair_fwd<WIENER>(T, tb, hi, lo, v2);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 S[j >> 1][j & 1] = v2[j].x;
@@ -589,7 +586,7 @@ __device__ __forceinline__ bool process_half_group(
 #pragma unroll
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
                 if (kl + 1 < KH) gather8v2(pair_r, 2 * corner_of(kb + kl + 1), voff, a, b);
-                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
+                pair_fwd<WIENER>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -605,7 +602,7 @@ __device__ __forceinline__ bool process_half_group(
                 for (int j = 0; j < 8; j++) v2[j] = mk2(a[j], b[j]);
                 gather8v(basic_r, corner_of(kb + kl), voff, a);
                 gather8v(basic_r, corner_of(kb + kl + 1), voff, b);
-                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
+                pair_fwd<WIENER>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     S[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -617,7 +614,7 @@ __device__ __forceinline__ bool process_half_group(
                     gather8v(noisy_r, corner_of(kb + kl + 2), voff, a);
                     gather8v(noisy_r, corner_of(kb + kl + 3), voff, b);
                 }
-                pair_fwd<C::HALFTB>(T, tb, hi, lo, v2);
+                pair_fwd<WIENER>(T, tb, hi, lo, v2);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     SB[j >> 1][2 * kl + (j & 1)] = v2[j].x;
@@ -724,7 +721,7 @@ __device__ __forceinline__ bool process_half_group(
             // the Wiener kernel has no registers to spare for the window between groups: its 8
             // values per lane are re-read here (2 KB table, L1-resident)
 #pragma unroll
-            for (int y = 0; y < 8; y++) ww[y] = (double)(w * win_g[(hi * 8 + y) * 8 + lo]) * up;
+            for (int y = 0; y < 8; y++) ww[y] = (double)(w * win_g[(hi * 8 + y) * 8 + xl]) * up;
         } else {
 #pragma unroll
             for (int y = 0; y < 8; y++) ww[y] = (double)(w * win[y]) * up;
@@ -785,7 +782,7 @@ __device__ __forceinline__ bool process_half_group(
         auto ring_off = [&](int k) -> int {
             int slot = __builtin_amdgcn_readlane(my_slot0, k) + hi;
             slot -= slot >= HNPL ? HNPL : 0;
-            return slot * HPS + __builtin_amdgcn_readlane(my_yx, k) + lo;
+            return slot * HPS + __builtin_amdgcn_readlane(my_yx, k) + xl;
         };
         auto ring_add = [&](int off, const f2 (&v)[8], int comp) {
             // lock-free: 64-bit integer LDS atomics, no return value.  term = rint(est * ww), the exact
@@ -805,7 +802,7 @@ __device__ __forceinline__ bool process_half_group(
                     v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl + 2 + (j & 1)]);
                     w2[j] = mk2(S[j >> 1][2 * kl + 4 + (j & 1)], S[j >> 1][2 * kl + 6 + (j & 1)]);
                 }
-                pair_inv_x2<C::HALFTB>(T, tb, hi, lo, v2, w2);
+                pair_inv_x2<WIENER>(T, tb, hi, lo, v2, w2);
                 STAMP(tl1);
                 gate(kb + kl);
                 ring_add(ring_off(kb + kl), v2, 0);
@@ -826,7 +823,7 @@ __device__ __forceinline__ bool process_half_group(
 #pragma unroll
                 for (int j = 0; j < 8; j++)
                     v2[j] = mk2(S[j >> 1][2 * kl + (j & 1)], S[j >> 1][2 * kl2 + (j & 1)]);
-                pair_inv<C::HALFTB>(T, tb, hi, lo, v2);
+                pair_inv<WIENER>(T, tb, hi, lo, v2);
                 STAMP(tl1);
                 gate(kb + kl);
                 ring_add(ring_off(kb + kl), v2, 0);
@@ -928,7 +925,7 @@ __global__ __launch_bounds__(HalfCfg<WIENER>::NW * 64) void stage_half_kernel(
     if constexpr (!WIENER) {
         const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
-        for (int y = 0; y < 8; y++) win[y] = win_g[(hi * 8 + y) * 8 + lo];
+        for (int y = 0; y < 8; y++) win[y] = win_g[(hi * 8 + y) * 8 + tr_x<WIENER>(hi, lo)];    // the x this lane adds (dct_pairs.h)
     }
     __syncthreads();
 
