@@ -216,11 +216,13 @@ __device__ __forceinline__ long long magic_bits(double m) {
     const unsigned hi = (unsigned)(b >> 32) - 0x43380000u;
     return (long long)(((unsigned long long)hi << 32) | (b & 0xFFFFFFFFull));
 }
-// R(d) of DESIGN.md 3.7 for two values at once: integer-subtraction seed (5 % off), one cubic step
-// r (1 + t + t^2), one Newton step -- five fused multiply-adds (v_pk_fma_f32), IEEE operations only, so the
-// oracle produces the same bits (v_rcp_f32 is a table the CPU does not have), and about what two quarter-rate
-// v_rcp_f32 cost.  (Measured at 1024^3, Wiener stage: v_rcp_f32 233.1 ms, two Newton steps 232.1, three 239.6;
-// the chains of two coefficient pairs are interleaved -- EXABM4D_WIE_ILV -- 239.6 -> 235.4.)
+// R(d) of DESIGN.md 3.7 for two values at once: integer-subtraction seed (5 % off), three Newton steps as fused
+// multiply-adds (v_pk_fma_f32) -- IEEE operations only, so the oracle produces the same bits (v_rcp_f32 is a
+// table the CPU does not have), and about what two quarter-rate v_rcp_f32 cost.  Measured at 1024^3, Wiener
+// stage, A/B on one box each: v_rcp_f32 233.1 ms, two Newton steps 232.1, three 239.6; with the chains of two
+// coefficient pairs interleaved (EXABM4D_WIE_ILV) 239.6 -> 235.4.  A five-operation form -- one cubic step
+// r (1 + t + t^2) and one Newton step, 0.8 ulp -- was built into specification, oracle and kernel and measured
+// SLOWER than the six operations of three Newton steps (235.9 against 233.8, A/B/A/B): reverted.
 #ifndef EXABM4D_WIE_ILV
 #define EXABM4D_WIE_ILV 2                      // Newton chains interleaved per scheduling region (0: no limit)
 #endif
@@ -228,14 +230,13 @@ __device__ __forceinline__ long long magic_bits(double m) {
 #define EXABM4D_WIE_RCP 0                      // 1 (timing probe, wrong bits): v_rcp_f32 as in rounds 1-3
 #endif
 __device__ __forceinline__ f2 rcp_nr2(f2 d) {
-#if EXABM4D_WIE_RCP
+#if EXABM4D_WIE_RCP == 1
     return mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
 #endif
     f2 r = mk2(__uint_as_float(0x7EF311C7u - __float_as_uint(d.x)), __uint_as_float(0x7EF311C7u - __float_as_uint(d.y)));
-    f2 t = __builtin_elementwise_fma(-d, r, (f2)(1.0f));
-    r = __builtin_elementwise_fma(__builtin_elementwise_fma(t, t, t), r, r);
-    t = __builtin_elementwise_fma(-d, r, (f2)(1.0f));
-    return __builtin_elementwise_fma(t, r, r);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r = __builtin_elementwise_fma(__builtin_elementwise_fma(-d, r, (f2)(1.0f)), r, r);
+    return r;
 }
 // W = e * R(e + sigma^2) and this lane's share of sum W^2: bits(fl(1 + W^2)) accumulated as integers --
 // each is 0x3F800000 + W^2 in units of 2^-23; the caller takes the 0x3F800000s off again (WSQ_BIAS per call)

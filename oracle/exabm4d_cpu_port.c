@@ -369,10 +369,10 @@ static void one_group(const float* noisy, const float* basic, const uint32_t* kk
             rb = 0x7EF311C7u - rb;
             float r;
             memcpy(&r, &rb, 4);
-            float t = fmaf(-d, r, 1.0f);
-            r = fmaf(fmaf(t, t, t), r, r);
-            t = fmaf(-d, r, 1.0f);
-            r = fmaf(t, r, r);
+            for (int it = 0; it < 3; it++) {
+                const float t = fmaf(-d, r, 1.0f);
+                r = fmaf(t, r, r);
+            }
             const float W = e * r;
             g[i] = W * g[i];
             const float t1 = fmaf(W, W, 1.0f);
