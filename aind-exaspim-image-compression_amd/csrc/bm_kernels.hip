@@ -58,8 +58,9 @@ struct TileShape {
 // and 7 wait for done >= tz before they read / overwrite a slot.
 // ORDER (round 4): a workgroup does not take its tile from blockIdx -- HIP does not promise that workgroups
 // start in id order -- but from a TICKET: thread 0 draws `atomicAdd(ticket, 1)` when the workgroup starts,
-// and the ticket goes through the slab-order map (xcd_slab_sync).  The producer of a tile's carry is the
-// same slab position one slab earlier: ticket - 8 q.  A smaller ticket has been drawn earlier, so its
+// and the ticket goes through the slab-order map (xcd_slab_sync; one ticket sequence per XCD, launch_position).
+// The producer of a tile's carry is the same slab position one slab earlier: q tickets back in the same
+// sequence.  A smaller ticket of a sequence has been drawn earlier, so its
 // workgroup is resident or finished, and it in turn only waits for a smaller ticket still: by induction
 // every wait ends, whatever order the hardware dispatches in (the look-back argument of rocPRIM's scans).
 // The poll is bounded all the same (CARRY_POLL_LIMIT, seconds): on expiry the wave raises bit 0 of the
@@ -76,7 +77,7 @@ struct Carry {
     int strip;               // tile order inside a slab: strips of this many tile rows, column-major (0 = raster)
     uint32_t* buf;           // [2][columns][CARRY_TILE]
     int* done;               // [columns]: tiles of the column that have finished (zeroed per launch)
-    int* ticket;             // the launch's ticket counter (zeroed per launch), see ORDER above
+    int* ticket;             // the launch's eight ticket counters (zeroed per launch), see ORDER above and launch_position
     unsigned* status;        // host-visible status word of the context: bit 0 = a carry wait ran out
     int fault;               // debug option "bm_carry_fault": every wait counts as run out (tests of the error path)
 };
@@ -109,12 +110,29 @@ __device__ __forceinline__ void carry_wait_for(const int* done, int tiles, int l
     }
 }
 // The workgroup's position in the launch order: its ticket when tiles carry (see ORDER), else its id.
-__device__ __forceinline__ int launch_position(const Carry& carry) {
+// EIGHT ticket counters, one per XCD sequence of the slab order (position = 8 j + c: XCD c's j-th tile): a
+// workgroup draws from the counter of the XCD it runs on (HW_REG_XCC_ID), so that the tiles an XCD works on
+// stay neighbours in ITS L2 -- one global counter handed consecutive tickets to whichever XCD asked first
+// and cost block matching its cache sharing (PMC: 43 -> 151 GB and 152 -> 280 GB per 1024^3 launch,
+// 116 -> 120-128 ms for the fp32 kernel).  A launch has exactly `quota` positions per sequence; should the
+// hardware give an XCD more workgroups than that, the surplus ones draw from the other sequences in turn
+// (8 * quota workgroups, 8 * quota positions: everybody finds one, every position is taken).  The order
+// argument holds per counter: a tile's producer is ticket j - q of the SAME counter, drawn earlier.
+__device__ __forceinline__ int launch_position(const Carry& carry, int quota) {
     if (!carry.on) return (int)blockIdx.x;
-    __shared__ int s_ticket;
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(carry.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int s_pos;
+    if (threadIdx.x == 0) {
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7);     // HW_REG_XCC_ID
+        int pos = -1;
+        for (int k = 0; k < 8 && pos < 0; k++) {
+            const int c = (xcc + k) & 7;
+            const int j = __hip_atomic_fetch_add(carry.ticket + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (j < quota) pos = 8 * j + c;
+        }
+        s_pos = pos;      // (-1 cannot happen: as many workgroups as positions; treated as padding)
+    }
     __syncthreads();
-    return s_ticket;
+    return s_pos;
 }
 
 // Each WAVE (= one z-layer of 8x8 cells) streams the candidate planes it needs through its own
@@ -143,7 +161,8 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
     const int per = tiles_y * tiles_x, cols = per * nbatch;
     int tz, col;
     if (xcd_q) {
-        const int t = xcd_slab_sync(launch_position(carry), cols, xcd_q);
+        const int lp = launch_position(carry, (int)(gridDim.x >> 3));
+        const int t = lp < 0 ? -1 : xcd_slab_sync(lp, cols, xcd_q);
         if (t < 0) return;                         // padding of the slab order
         tz = t / cols;
         col = t - tz * cols;
@@ -513,7 +532,8 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
     const int per = tiles_y * tiles_x, cols = per * nbatch;
     int tz, col;
     if (xcd_q) {
-        const int t = xcd_slab_sync(launch_position(carry), cols, xcd_q);
+        const int lp = launch_position(carry, (int)(gridDim.x >> 3));
+        const int t = lp < 0 ? -1 : xcd_slab_sync(lp, cols, xcd_q);
         if (t < 0) return;                         // padding of the slab order
         tz = t / cols;
         col = t - tz * cols;
@@ -943,8 +963,8 @@ hipError_t launch_blockmatch(const float* vol, const VolGeom& g, int batch, uint
         carry.ticket = p.carry ? carry.done + cols : nullptr;
         carry.status = status;
         carry.fault = p.fault;
-        if (p.carry) {      // done[columns] and the ticket counter behind it
-            hipError_t e = hipMemsetAsync(carry.done, 0, (cols + 1) * sizeof(int), stream);
+        if (p.carry) {      // done[columns] and the eight ticket counters behind it
+            hipError_t e = hipMemsetAsync(carry.done, 0, (cols + 8) * sizeof(int), stream);
             if (e != hipSuccess) return e;
         }
         dim3 grid((unsigned)(p.xq ? 8 * p.xq * p.tz : p.tz * p.ty * p.tx), (unsigned)(p.xq ? 1 : batch));
