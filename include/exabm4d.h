@@ -173,7 +173,7 @@ int exabm4d_grid_positions(int n, int32_t* pos);
 int exabm4d_tables(const exabm4d_params* p, float* dct64, float* win512);
 /* Bytes of device scratch an exabm4d_denoise_*_dev call of this shape takes from the context (match table,
  * 64-bit numerator and corner-weight sums, basic estimate, work volumes, and -- since round 4 -- the 744 KB per
- * tile column of block matching's carry where the default options use it: 1.0 GB of 27 GB at 1024^3), under
+ * tile column of block matching's carry where the default options use it: 1.0 GB of 36.4 GB at 1024^3), under
  * the default options; the uint16 entry points add the fp32 + uint16 counts (6 bytes per voxel). */
 size_t exabm4d_scratch_bytes(int nz, int ny, int nx, int batch, int stages);
 
