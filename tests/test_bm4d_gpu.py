@@ -286,6 +286,9 @@ def test_other_sigma_and_profile(ctx, oracle):
     np.testing.assert_array_equal(got, want)
     big = (vol * np.float32(3.0e7)).astype(np.float32)         # ... and data far above the uint16 range (E = 38)
     np.testing.assert_array_equal(ctx.denoise_f32_host(big, SIGMA * 3.0e7), oracle.bm4d(big, SIGMA * 3.0e7))
+    for k in (-60, 70):        # the unit follows the data over 130 binades (E = -48 ... 83)
+        v = (vol * np.float32(2.0 ** k)).astype(np.float32)
+        np.testing.assert_array_equal(ctx.denoise_f32_host(v, SIGMA * 2.0 ** k), oracle.bm4d(v, SIGMA * 2.0 ** k))
     p = nat.default_params(kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
     got = ctx.denoise_f32_host(vol, SIGMA, params=p)
     want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)

@@ -10,6 +10,8 @@ Every iteration draws a shape (8..72 per axis, ragged and even / odd row lengths
     sums are integers; rounds 1-3 allowed a count, and an "account" of changed stage-2 groups beyond it),
     also with the stage kernels' launch shape drawn at random (z chunks, tile order, gather form) and on
     a second launch,
+  * the fp32 entry point on the same counts at a random scale (2^-40 ... 2^50: the numerator's unit follows the
+    data), one or two stages, clipped or not: the oracle's fp32 volume, bit for bit,
   * the chunk coder on a random chunk grid: bytes identical to the C restatement, exact decode.
 Prints one line per iteration and a summary; exit code 1 on the first mismatch."""
 import os
@@ -100,7 +102,15 @@ def main():
         ctx.denoise_u16(d_vol, d_out, shape, sigma, offset)                 # again: a function of its input
         ok_pipe = not d.any() and np.array_equal(d_out.download(shape, np.uint16), got)
         note = ""
-        del f
+        # the fp32 entry point on the same counts at a random scale: every volume carries its own unit
+        # (E from its largest |v|) -- one stage or two, clipped or not
+        scale = np.float32(rng.choice([1.0, 1.0 / 4096.0, 3.0e4, 2.0 ** -40, 2.0 ** 50]))
+        g32 = (f * scale).astype(np.float32)
+        st = int(rng.integers(1, 3))
+        clip = None if rng.random() < 0.5 else (0.0, float(np.float32(20000.0) * scale))
+        got32 = ctx.denoise_f32_host(g32, float(np.float32(sigma) * scale), stages=st, clip=clip)
+        ok_f32 = np.array_equal(got32, O.bm4d(g32, float(np.float32(sigma) * scale), stages=st, clip=clip))
+        del f, g32
 
         # chunk coder on the denoised volume, random chunk grid
         chunk = tuple(int(rng.choice([8, 16, 24, 64])) for _ in range(3))
@@ -118,8 +128,8 @@ def main():
         print(f"{it:4d} {name:9s} {str(shape):14s} sigma {sigma:5.1f} offset {offset:5.1f} chunk {chunk} "
               f"keys {'ok' if ok_keys else 'MISMATCH'} pipeline max|d| {int(d.max())} "
               f"frac {float(np.mean(d > 0)):.1e} beyond one {float(np.mean(d > 1)):.1e} {'ok' if ok_pipe else 'MISMATCH'}{note} "
-              f"codec {'ok' if ok_codec else 'MISMATCH'}", flush=True)
-        if not (ok_keys and ok_pipe and ok_codec):
+              f"codec {'ok' if ok_codec else 'MISMATCH'} f32 x{float(scale):.3g} {'ok' if ok_f32 else 'MISMATCH'}", flush=True)
+        if not (ok_keys and ok_pipe and ok_codec and ok_f32):
             np.save(os.path.join(ROOT, "gpurun_out", "fuzz_fail_vol.npy"), vol)
             print("FAILED", flush=True)
             return 1
