@@ -464,6 +464,9 @@ __global__ __launch_bounds__(512) void bm_tile_kernel(const float* __restrict__ 
 
     if (ref_ok) {
         uint32_t* out = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
+        // never empty: a block with an infinity or a NaN in it has no admissible distance, not
+        // even to itself; it forms the one-block group of key 0, so that every key downstream names a block
+        list[0] = list[0] == KEY_EMPTY ? 0u : list[0];
 #pragma unroll
         for (int k = 0; k < MAXG; k += 4) {
             uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
@@ -788,6 +791,9 @@ __global__ __launch_bounds__(512) void bm_tile16_kernel(const uint16_t* __restri
 
     if (ref_ok) {
         uint32_t* out = keys + ((size_t)((size_t)iz * g.gy + iy) * g.gx + ix) * MAXG;
+        // never empty: a block with an infinity or a NaN in it has no admissible distance, not
+        // even to itself; it forms the one-block group of key 0, so that every key downstream names a block
+        list[0] = list[0] == KEY_EMPTY ? 0u : list[0];
 #pragma unroll
         for (int k = 0; k < MAXG; k += 4) {
             uint4 v = make_uint4(list[k], list[k + 1], list[k + 2], list[k + 3]);
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(64) void bm_generic_kernel(const float* __restrict_
             for (int i = 0; i < MAXG - 1; i++) list[i] = list[i + 1];
             list[MAXG - 1] = KEY_EMPTY;
         }
-        if (lane == 0) out[k] = m;
+        if (lane == 0) out[k] = (k == 0 && m == KEY_EMPTY) ? 0u : m;      // never empty
     }
 }
 

@@ -703,15 +703,19 @@ __global__ __launch_bounds__(EW_THREADS) void absmax_bits_kernel(const float* __
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits + blockIdx.y, m);
 }
 __global__ void qscale_kernel(const unsigned* __restrict__ maxbits, int batch, int fixed_exp,
-                              double* __restrict__ qscale) {
+                              double* __restrict__ qscale, unsigned* __restrict__ status) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const int E = fixed_exp != INT32_MIN ? fixed_exp : (int)(maxbits[b] >> 23) - 126;
+    // DESIGN.md 3.8, domain: beyond |v| < 2^56 the squares of transform coefficients (|Y| <= sqrt(8192) max|v|)
+    // and of voxel differences leave fp32; infinities and NaNs land here too.  The pipeline still runs (no
+    // fault, garbage out); the host reports EXABM4D_ERR_INVALID at its next synchronisation (status bit 1).
+    if (E > 56 && status) __hip_atomic_fetch_or(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     qscale[2 * b] = ldexp(1.0, 43 - E);
     qscale[2 * b + 1] = ldexp(1.0, E - 43);
 }
 hipError_t launch_qscale(const float* vol, size_t nvox, int batch, int fixed_exp, unsigned* maxbits,
-                         double* qscale, hipStream_t s) {
+                         double* qscale, hipStream_t s, unsigned* status) {
     if (fixed_exp == INT32_MIN) {
         hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned) * (size_t)batch, s);
         if (e != hipSuccess) return e;
@@ -721,7 +725,7 @@ hipError_t launch_qscale(const float* vol, size_t nvox, int batch, int fixed_exp
                            nvox, maxbits);
     }
     hipLaunchKernelGGL(qscale_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, s, maxbits, batch, fixed_exp,
-                       qscale);
+                       qscale, status);
     return hipGetLastError();
 }
 

@@ -183,6 +183,11 @@ static int check_async_status(exabm4d_ctx* ctx) {
                     "tiles, DESIGN.md 5.1c); the match tables of the calls since the last synchronisation are void. "
                     "The carry is now off for this context (option bm_carry = 0): repeat the call.");
     }
+    if (bits & 2u)
+        return fail(ctx, EXABM4D_ERR_INVALID,
+                    "fp32 input outside the working range of the specification: a volume holds |v| >= 2^56, an "
+                    "infinity or a NaN (the squares of its transform coefficients leave fp32, DESIGN.md 3.8); the "
+                    "results of the calls since the last synchronisation are void");
     return fail(ctx, EXABM4D_ERR_HIP, "a kernel reported an unknown status bit");
 }
 
@@ -643,7 +648,7 @@ int exabm4d_stage_dev(exabm4d_ctx* ctx, const float* noisy, const float* basic,
     double* qs = reinterpret_cast<double*>(sc + o_qs);
     HIP_TRY(ctx, hipMemsetAsync(sc + o_num, 0, o_tmp, ctx->stream));       // numerator and corner weights
     HIP_TRY(ctx, launch_qscale(noisy, (size_t)g.nvox, batch, data_exp, reinterpret_cast<unsigned*>(sc + o_mb), qs,
-                               ctx->stream));
+                               ctx->stream, ctx->status_dev));
     HIP_TRY(ctx, launch_stage(noisy, basic, keys, g, batch, ctx->dct, ctx->win_dev, thr, sigma2, qs, numq, cw,
                               ctx->stream, ctx->stage, basic ? reinterpret_cast<float*>(sc + o_pair) : nullptr, 0));
     HIP_TRY(ctx, launch_num_to_float(numq, qs, num, (size_t)g.nvox, batch, ctx->stream));
@@ -738,7 +743,7 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         HIP_TRY(ctx, hipMemsetAsync(num, 0, n * sizeof(long long), s));
         HIP_TRY(ctx, hipMemsetAsync(cw, 0, n * sizeof(unsigned long long), s));
         HIP_TRY(ctx, launch_qscale(noisy, (size_t)g.nvox, batch, data_exp,
-                                   reinterpret_cast<unsigned*>(scratch + L.maxbits), qs, s));
+                                   reinterpret_cast<unsigned*>(scratch + L.maxbits), qs, s, ctx->status_dev));
     }
     {
         PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_HT);

@@ -93,7 +93,7 @@ hipError_t launch_stage(const float* noisy, const float* basic, const uint32_t* 
 // fixed_exp != INT32_MIN: E = fixed_exp for every volume (the uint16 entry points: 17); else E from the
 // largest |v| bit pattern of volume b of `vol` (maxbits: `batch` words of scratch).  No host synchronisation.
 hipError_t launch_qscale(const float* vol, size_t nvox, int batch, int fixed_exp, unsigned* maxbits,
-                         double* qscale, hipStream_t s);
+                         double* qscale, hipStream_t s, unsigned* status = nullptr);
 // den = fl32(cw 2^-40) (*) win for the separable window win = k (x) k (x) k: fused x / y pass cw -> tmp,
 // z pass tmp -> den (written).
 hipError_t launch_den_from_corners(const unsigned long long* cw, float* tmp, float* den, int nz, int ny, int nx,

@@ -233,7 +233,12 @@ int exabm4d_normalize_u16_dev(exabm4d_ctx* ctx, const float* num, const float* d
                               size_t n, float offset);
 
 /* ---- BM4D whole pipeline ------------------------------------------------------------------- */
-/* stages: 1 = hard-threshold only, 2 = hard-threshold + Wiener.  in/out may alias. */
+/* stages: 1 = hard-threshold only, 2 = hard-threshold + Wiener.  in/out may alias.
+ * Working range of the fp32 forms: finite data with max |v| < 2^56 per volume.  Outside it
+ * (the squares of transform coefficients leave fp32; infinities; NaNs) the kernels still run and stay inside
+ * their buffers, the device raises a status bit, and the next synchronising call on the context
+ * (exabm4d_denoise_f32_host itself, exabm4d_sync, exabm4d_memcpy_d2h, ...) returns EXABM4D_ERR_INVALID:
+ * the results since the last synchronisation are void.  The uint16 forms are always inside. */
 int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
                             int batch, float sigma, const exabm4d_params* p, int stages,
                             float clip_lo, float clip_hi);

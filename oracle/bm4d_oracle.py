@@ -149,6 +149,7 @@ def group_transform(g, inverse=False, port=False):
 
 AUTO_EXP = -2 ** 31      # data_exp: take E from the noisy volume (the fp32 entry points' rule)
 U16_DATA_EXP = 17        # E of the uint16 entry points
+MAX_DATA_EXP = 56        # fp32 entry points: beyond |v| < 2^56 squares of coefficients leave fp32
 
 
 def data_exp(vol):
@@ -217,6 +218,8 @@ def bm4d(vol, sigma, stages=2, clip=None, data_exp=None, **kw):
     p = {**DEFAULTS, **kw}
     vol = _f32(vol)
     nz, ny, nx = vol.shape
+    if data_exp is None and int(lib().orc_data_exp(_p(vol, ctypes.c_float), vol.size)) > MAX_DATA_EXP:
+        raise ValueError("fp32 volume outside the working range of DESIGN.md 3.8 (|v| >= 2^56, inf or NaN)")
     out = np.empty_like(vol)
     lo, hi = (1.0, 0.0) if clip is None else clip
     lib().orc_bm4d_e(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), nz, ny, nx, float(sigma),

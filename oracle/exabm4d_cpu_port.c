@@ -168,6 +168,7 @@ void cpu_blockmatch(const float* vol, int nz, int ny, int nx, float sigma, float
                         }
                     }
                 }
+                if (list[0] == KEY_EMPTY) list[0] = 0u;      /* never empty: DESIGN.md 3.4 */
                 memcpy(keys + ((size_t)((size_t)iz * gy + iy) * gx + ix) * MAXG, list, sizeof list);
             }
     }
@@ -204,6 +205,7 @@ void cpu_blockmatch(const float* vol, int nz, int ny, int nx, float sigma, float
                 }
             }
         }
+        if (list[0] == KEY_EMPTY) list[0] = 0u;
         memcpy(keys + (size_t)r * MAXG, list, sizeof list);
     }
     free(pz);

@@ -74,6 +74,23 @@ def test_blockmatch_generic_kernel_matches(ctx, oracle):
     np.testing.assert_array_equal(got, want)
 
 
+def test_blockmatch_tables_are_never_empty(ctx, oracle):
+    """blocks holding an infinity or a NaN get the one-entry table [0] (their distance to
+    themselves is not a number), all other tables are unchanged -- in both float kernels, as in the oracle."""
+    vol, _ = synth_volume((40, 44, 48), seed=6)
+    vol[5, 6, 7] = np.nan
+    vol[30, 33, 41] = -np.inf
+    vol[39, 43, 47] = np.inf
+    want = oracle.blockmatch(vol, SIGMA, 3.0)
+    assert (want[..., 0] == 0).all() and (want[1, 1, 1, 1:] == 0xFFFFFFFF).all()
+    np.testing.assert_array_equal(_keys_gpu(ctx, vol, SIGMA, 3.0), want)
+    ctx.set_option("force_generic_bm", 1)
+    try:
+        np.testing.assert_array_equal(_keys_gpu(ctx, vol, SIGMA, 3.0), want)
+    finally:
+        ctx.set_option("force_generic_bm", 0)
+
+
 def test_blockmatch_constant_volume_self_first(ctx, oracle):
     """All candidates tie at distance 0: the reference block itself must still be entry 0 and the
     rest ordered by displacement code."""
@@ -286,9 +303,33 @@ def test_other_sigma_and_profile(ctx, oracle):
     np.testing.assert_array_equal(got, want)
     big = (vol * np.float32(3.0e7)).astype(np.float32)         # ... and data far above the uint16 range (E = 38)
     np.testing.assert_array_equal(ctx.denoise_f32_host(big, SIGMA * 3.0e7), oracle.bm4d(big, SIGMA * 3.0e7))
-    for k in (-60, 70):        # the unit follows the data over 130 binades (E = -48 ... 83)
+    for k in (-60, 40):        # the unit follows the data over 100 binades (E = -46 ... 54)
         v = (vol * np.float32(2.0 ** k)).astype(np.float32)
+        assert oracle.data_exp(v) == oracle.data_exp(vol) + k
         np.testing.assert_array_equal(ctx.denoise_f32_host(v, SIGMA * 2.0 ** k), oracle.bm4d(v, SIGMA * 2.0 ** k))
+
+
+def test_fp32_input_outside_the_working_range_is_refused(ctx, oracle):
+    """DESIGN.md 3.8, domain: |v| >= 2^56 (squares of transform coefficients leave fp32), infinities and NaNs
+    are reported as EXABM4D_ERR_INVALID at the call's synchronisation -- by the device, which finds the
+    largest magnitude anyway; the oracle's wrapper refuses the same volumes.  The context stays usable."""
+    vol, _ = synth_volume((16, 24, 24), seed=21)
+    big = (vol * np.float32(2.0 ** (57 - oracle.data_exp(vol)))).astype(np.float32)       # E = 57
+    assert oracle.data_exp(big) > oracle.MAX_DATA_EXP
+    nan = vol.copy()
+    nan[3, 4, 5] = np.nan
+    inf = vol.copy()
+    inf[0, 0, 0] = -np.inf
+    for bad in (big, nan, inf):
+        with pytest.raises(ValueError, match="working range"):
+            ctx.denoise_f32_host(bad, SIGMA)
+        with pytest.raises(ValueError, match="working range"):
+            oracle.bm4d(bad, SIGMA)
+    edge = (vol * np.float32(2.0 ** (56 - oracle.data_exp(vol)))).astype(np.float32)      # E = 56: the last one in
+    assert oracle.data_exp(edge) == 56
+    s = SIGMA * 2.0 ** (56 - oracle.data_exp(vol))
+    np.testing.assert_array_equal(ctx.denoise_f32_host(edge, s), oracle.bm4d(edge, s))
+    np.testing.assert_array_equal(ctx.denoise_f32_host(vol, SIGMA), oracle.bm4d(vol, SIGMA))
     p = nat.default_params(kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
     got = ctx.denoise_f32_host(vol, SIGMA, params=p)
     want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)

@@ -359,3 +359,28 @@ def test_oracle_pipeline_against_the_independent_restatement(oracle):
     assert np.max(np.abs(oracle.bm4d(flat, SIGMA) - R.bm4d(flat, SIGMA))) < 1e-4
     dc2 = (5.0 * np.sqrt(512.0 * 16.0)) ** 2
     assert abs(float(oracle.bm4d(flat, SIGMA)[4, 4, 6]) - 5.0 * dc2 / (dc2 + SIGMA ** 2)) < 1e-4
+
+
+def test_match_tables_are_never_empty(oracle):
+    """a block that holds an infinity or a NaN has no admissible distance, not even to itself,
+    and gets the one-entry table [0]; every other table is what it was.  Oracle and CPU port agree, and the
+    C pipelines run through such a volume without touching anything they should not (keys name blocks)."""
+    vol, _ = synth_volume((16, 20, 24), seed=5)
+    want = oracle.blockmatch(vol, 24.0, 3.0)
+    assert (want[..., 0] == 0).all()
+    bad = vol.copy()
+    bad[5, 6, 7] = np.nan
+    bad[12, 15, 20] = np.inf
+    got = oracle.blockmatch(bad, 24.0, 3.0)
+    np.testing.assert_array_equal(got, oracle.blockmatch(bad, 24.0, 3.0, port=True))
+    assert (got[..., 0] == 0).all()
+    pos = [oracle.grid_positions(n) for n in bad.shape]
+    for iz, z in enumerate(pos[0]):
+        for iy, y in enumerate(pos[1]):
+            for ix, x in enumerate(pos[2]):
+                if not np.isfinite(bad[z:z + 8, y:y + 8, x:x + 8]).all():
+                    assert (got[iz, iy, ix, 1:] == 0xFFFFFFFF).all()
+    with pytest.raises(ValueError, match="working range"):
+        oracle.bm4d(bad, 24.0)
+    out = oracle.bm4d(bad, 24.0, data_exp=oracle.data_exp(vol))        # past the wrapper: runs, garbage out
+    assert out.shape == bad.shape
