@@ -307,6 +307,10 @@ def test_other_sigma_and_profile(ctx, oracle):
         v = (vol * np.float32(2.0 ** k)).astype(np.float32)
         assert oracle.data_exp(v) == oracle.data_exp(vol) + k
         np.testing.assert_array_equal(ctx.denoise_f32_host(v, SIGMA * 2.0 ** k), oracle.bm4d(v, SIGMA * 2.0 ** k))
+    p = nat.default_params(kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
+    got = ctx.denoise_f32_host(vol, SIGMA, params=p)
+    want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
+    np.testing.assert_array_equal(got, want)
 
 
 def test_fp32_input_outside_the_working_range_is_refused(ctx, oracle):
@@ -330,10 +334,6 @@ def test_fp32_input_outside_the_working_range_is_refused(ctx, oracle):
     s = SIGMA * 2.0 ** (56 - oracle.data_exp(vol))
     np.testing.assert_array_equal(ctx.denoise_f32_host(edge, s), oracle.bm4d(edge, s))
     np.testing.assert_array_equal(ctx.denoise_f32_host(vol, SIGMA), oracle.bm4d(vol, SIGMA))
-    p = nat.default_params(kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
-    got = ctx.denoise_f32_host(vol, SIGMA, params=p)
-    want = oracle.bm4d(vol, SIGMA, kaiser_beta=0.0, lambda_ht=3.0, c_match_ht=2.5, c_match_wie=0.4)
-    np.testing.assert_array_equal(got, want)
 
 
 def _keys_u16(ctx, vol, sigma, c_match, batch=1):
