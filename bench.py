@@ -719,6 +719,7 @@ ENV_OPTIONS = {                      # A/B switches of tools/dbg: environment va
     "EXABM4D_STAGE_PAIRVOL": "stage_pairvol",    # Wiener gathers from the interleaved (noisy, basic) volume
     "EXABM4D_BM_CARRY": "bm_carry",              # block matching: carry between the tiles of a column
     "EXABM4D_BM_XCD_MODE": "bm_xcd_mode",        # block matching: workgroup order
+    "EXABM4D_ZERO_OVERLAP": "zero_overlap",      # the sums' memsets under block matching (second stream) or in line
 }
 
 

@@ -129,7 +129,9 @@ int exabm4d_default_params(exabm4d_params* p);
  * instead of hanging, the next synchronising call (exabm4d_sync, exabm4d_memcpy_d2h, *_host, ...) returns
  * EXABM4D_ERR_HIP, and the carry is off for that context from then on (exabm4d_denoise_f32_host repeats its
  * run without the carry by itself).  "bm_carry_fault" = 1 (debug) makes every such wait count as run out; "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
- * block matching; "stage_strip" = 0 | n (default 3): tile-column order of the stage
+ * block matching; "zero_overlap" = 0 | 1 (default 1): the 8-byte sums are zeroed on a second
+ * stream of the context's, under the block matching that precedes each stage kernel, instead of in line
+ * (DESIGN.md 5.3); "stage_strip" = 0 | n (default 3): tile-column order of the stage
  * kernels (0 = raster, n = strips of n tile rows; the same results, bit for bit: the sums are integers).
  * Every option belongs to the context it is set on (round 4; rounds 1-3 kept some in process globals). */
 int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value);
