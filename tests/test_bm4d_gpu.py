@@ -236,6 +236,29 @@ def test_pipeline_u16(ctx, oracle):
     np.testing.assert_array_equal(d_out.download(shape, np.uint16), want)
 
 
+def test_calls_queued_back_to_back_and_the_zeroing_stream(ctx, oracle):
+    """The 8-byte sums are zeroed on a second stream under block matching (option
+    ``zero_overlap``).  Calls queued without a synchronisation between them share the sums' memory: the
+    zeroing of call k + 1 must wait for the last reader of call k.  Same bits in line and overlapped."""
+    shape = (40, 44, 48)
+    vols = [synth_volume(shape, seed=s, as_u16=True)[0] for s in (61, 62, 63)]
+    want = [oracle.bm4d_u16(v, SIGMA, 37.0) for v in vols]
+    d_in = [ctx.to_device(v) for v in vols]
+    d_out = [ctx.alloc(v.nbytes) for v in vols]
+    for overlap in (1, 0, 1):
+        ctx.set_option("zero_overlap", overlap)
+        try:
+            for d in d_out:
+                d.fill(0xEE)
+            for i in range(3):
+                ctx.denoise_u16(d_in[i], d_out[i], shape, SIGMA, 37.0)
+            ctx.sync()
+        finally:
+            ctx.set_option("zero_overlap", 1)
+        for i in range(3):
+            np.testing.assert_array_equal(d_out[i].download(shape, np.uint16), want[i])
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 8), (8, 9, 12), (12, 8, 8), (9, 9, 9), (16, 8, 20),
                                    (8, 64, 8), (13, 11, 10)])
 def test_tiny_and_thin_volumes_full_pipeline(ctx, oracle, shape):
