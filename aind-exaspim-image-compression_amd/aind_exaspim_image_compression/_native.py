@@ -114,6 +114,9 @@ SIGNATURES = {
     "exabm4d_blockmatch_plan": (_I, [_CTX, _I, _I, _I, _I, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint64)]),
     "exabm4d_denoise_chunked_u16_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _I, _F, _F, _PP, _I]),
     "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
+    "exabm4d_denoise_f32_host_v": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
+    "exabm4d_host_register": (_I, [_CTX, c_vp, ctypes.c_size_t]),
+    "exabm4d_host_unregister": (_I, [_CTX, c_vp]),
     "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
     "exabm4d_transform_forward_f32_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
     "exabm4d_transform_inverse_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
@@ -455,6 +458,29 @@ class Context:
                                                    float(hi)))
         return out
 
+    def host_register(self, addr, nbytes):
+        """Page-lock caller memory that host entry points copy from / to repeatedly (see the header)."""
+        self._check(lib().exabm4d_host_register(self.handle, int(addr), int(nbytes)))
+
+    def host_unregister(self, addr):
+        self._check(lib().exabm4d_host_unregister(self.handle, int(addr)))
+
+    def denoise_f32_host_v(self, in_addrs, out_addrs, shape, sigma, params=None, stages=2, clip=None):
+        """A batch of fp32 volumes of ``shape`` that lie anywhere in host memory: ``in_addrs[i]`` /
+        ``out_addrs[i]`` are the addresses of volume i (they may be equal: in place).  The caller keeps the
+        memory alive and writable; nothing is allocated or copied on the host side."""
+        if len(in_addrs) != len(out_addrs) or not len(in_addrs):
+            raise ValueError("one input and one output address per volume")
+        p = params or default_params()
+        nz, ny, nx = (int(s) for s in shape)
+        n = len(in_addrs)
+        ins = (ctypes.c_void_p * n)(*[int(a) for a in in_addrs])
+        outs = (ctypes.c_void_p * n)(*[int(a) for a in out_addrs])
+        lo, hi = (1.0, 0.0) if clip is None else clip
+        self._check(lib().exabm4d_denoise_f32_host_v(self.handle, ctypes.cast(ins, c_vp), ctypes.cast(outs, c_vp),
+                                                     nz, ny, nx, n, float(sigma), ctypes.byref(p), int(stages),
+                                                     float(lo), float(hi)))
+
     # -- transforms ---------------------------------------------------------------------------
     def transform_forward(self, tf, src, dst, n, src_is_u16):
         fn = (lib().exabm4d_transform_forward_u16_dev if src_is_u16
@@ -666,6 +692,13 @@ def context(device=None):
             if _hip_owner_pid is None:
                 _hip_owner_pid = os.getpid()
     return ctx
+
+
+def new_context(device=None):
+    """One MORE context of the calling process on ``device`` (its own stream and scratch): for callers that keep
+    several device calls in flight from several threads (the broker).  Not cached; the caller keeps it."""
+    first = context(device)                 # the fork checks, and the process's cached context
+    return Context(first.device)
 
 
 def check_host_volume_pair(src, dst):

@@ -1147,6 +1147,61 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     }
 }
 
+// The same for a batch whose volumes lie anywhere in host memory (the broker's shape: every caller's patch in
+// its own shared-memory segment): in[i] / out[i] per volume, out[i] may be in[i].
+int exabm4d_denoise_f32_host_v(exabm4d_ctx* ctx, const float* const* in, float* const* out, int nz, int ny,
+                               int nx, int batch, float sigma, const exabm4d_params* p, int stages,
+                               float clip_lo, float clip_hi) {
+    VolGeom g;
+    int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
+    if (rc) return rc;
+    for (int b = 0; b < batch; b++)
+        if (!in[b] || !out[b]) return fail(ctx, EXABM4D_ERR_INVALID, "NULL volume pointer");
+    const size_t nv = (size_t)g.nvox, n = nv * (size_t)batch;
+    for (int attempt = 0;; attempt++) {
+        const size_t base = pipe_bytes(ctx->bm, nz, ny, nx, batch, stages);
+        rc = ensure_scratch(ctx, base + align256(n * sizeof(float)));
+        if (rc) return rc;
+        char* scratch = static_cast<char*>(ctx->scratch);
+        float* vol = reinterpret_cast<float*>(scratch + base);
+        for (int b = 0; b < batch; b++)
+            HIP_TRY(ctx, hipMemcpyAsync(vol + (size_t)b * nv, in[b], nv * sizeof(float), hipMemcpyHostToDevice,
+                                        ctx->stream));
+        rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
+                          scratch, 1, EXABM4D_DATA_EXP_AUTO);
+        if (rc) return rc;
+        // (a repeated run reads in[] again: the results go to the host only once the run is known to be good)
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        rc = check_async_status(ctx);
+        if (rc != EXABM4D_OK) {
+            if (attempt == 1 || ctx->bm.carry != 0) return rc;
+            continue;
+        }
+        for (int b = 0; b < batch; b++)
+            HIP_TRY(ctx, hipMemcpyAsync(out[b], vol + (size_t)b * nv, nv * sizeof(float), hipMemcpyDeviceToHost,
+                                        ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return EXABM4D_OK;
+    }
+}
+
+// Page-lock caller memory that host entry points will copy from / to many times (the broker: every worker's
+// shared-memory segment, for the life of the connection): the copies then are DMA transfers instead of staged
+// ones.  hipHostRegisterDefault; the mapping is per process, the registration per (pointer, size).
+int exabm4d_host_register(exabm4d_ctx* ctx, void* ptr, size_t bytes) {
+    if (!ctx || !ptr || !bytes) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument or empty range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return EXABM4D_OK;
+}
+int exabm4d_host_unregister(exabm4d_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipHostUnregister(ptr));
+    return EXABM4D_OK;
+}
+
 int exabm4d_profile_read(exabm4d_ctx* ctx, float* ms, int max_phases) {
     if (!ctx || !ms) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
     if (!ctx->ev[0]) return fail(ctx, EXABM4D_ERR_INVALID, "profiling was never enabled");

@@ -282,6 +282,18 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
 int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
                              int batch, float sigma, const exabm4d_params* p, int stages,
                              float clip_lo, float clip_hi);
+/* The same for a batch of `batch` volumes that lie anywhere in host memory: in[i] / out[i] point to volume i
+ * ([nz][ny][nx] fp32; out[i] may be in[i]).  What the per-device broker calls with every worker's patch in that
+ * worker's own shared-memory segment (broker.py; reference scripts/precompute.py:215-228: one bm4d(raw, sigma)
+ * per 64^3 patch and worker).  Per volume the result of exabm4d_denoise_f32_host. */
+int exabm4d_denoise_f32_host_v(exabm4d_ctx* ctx, const float* const* in, float* const* out, int nz, int ny,
+                               int nx, int batch, float sigma, const exabm4d_params* p, int stages,
+                               float clip_lo, float clip_hi);
+/* Page-lock `bytes` of caller memory at `ptr` that the host entry points will copy from / to repeatedly (the
+ * broker registers every worker's shared-memory segment once): copies become DMA transfers instead of staged
+ * ones.  Unregister before the memory is unmapped. */
+int exabm4d_host_register(exabm4d_ctx* ctx, void* ptr, size_t bytes);
+int exabm4d_host_unregister(exabm4d_ctx* ctx, void* ptr);
 
 /* ---- multi-GPU: halo exchange over RCCL (north_star "RCCL over xGMI only for halo
  * exchange at chunk borders") ------------------------------------------------------------------------------

@@ -236,6 +236,27 @@ def test_pipeline_u16(ctx, oracle):
     np.testing.assert_array_equal(d_out.download(shape, np.uint16), want)
 
 
+def test_host_batch_of_scattered_volumes(ctx, oracle):
+    """exabm4d_denoise_f32_host_v: one pointer per volume (the broker's call, every worker's patch in its own
+    segment): per volume the result of the contiguous host call, in place and out of place."""
+    shape = (24, 28, 32)
+    vols = [synth_volume(shape, seed=70 + i)[0] * np.float32(1 + i) for i in range(5)]
+    want = ctx.denoise_f32_host(np.stack(vols), SIGMA, clip=(0.0, 65535.0))
+    np.testing.assert_array_equal(want[3], np.clip(oracle.bm4d(vols[3], SIGMA), 0, 65535))
+    outs = [np.full(shape, -1, dtype=np.float32) for _ in vols]
+    ctx.denoise_f32_host_v([v.ctypes.data for v in vols], [o.ctypes.data for o in outs], shape, SIGMA,
+                           clip=(0.0, 65535.0))
+    for i in range(5):
+        np.testing.assert_array_equal(outs[i], want[i])
+    work = [v.copy() for v in vols]
+    addrs = [w.ctypes.data for w in work]
+    ctx.denoise_f32_host_v(addrs, addrs, shape, SIGMA, clip=(0.0, 65535.0))
+    for i in range(5):
+        np.testing.assert_array_equal(work[i], want[i])
+    with pytest.raises(ValueError):
+        ctx.denoise_f32_host_v(addrs[:2], addrs[:1], shape, SIGMA)
+
+
 def test_calls_queued_back_to_back_and_the_zeroing_stream(ctx, oracle):
     """The 8-byte sums are zeroed on a second stream under block matching (option
     ``zero_overlap``).  Calls queued without a synchronisation between them share the sums' memory: the

@@ -53,17 +53,22 @@ def test_split_and_batch_plans():
 
 
 class _FakeContext:
-    """Stand-in for the device: 'denoising' = x / 2 + sigma, per volume; records the batch sizes."""
+    """Stand-in for the device: 'denoising' = x / 2 + sigma, per volume, in place at the addresses the broker
+    hands over (the interface of Context.denoise_f32_host_v); records the batch sizes."""
 
     def __init__(self):
         self.batches = []
 
-    def denoise_f32_host(self, vols, sigma, params=None, stages=2, clip=None):
-        vols = np.asarray(vols, dtype=np.float32)
-        self.batches.append(vols.shape[0] if vols.ndim == 4 else 1)
+    def denoise_f32_host_v(self, in_addrs, out_addrs, shape, sigma, params=None, stages=2, clip=None):
+        import ctypes
+        self.batches.append(len(in_addrs))
         time.sleep(0.02)                                   # long enough for the other workers to queue up
-        out = vols * np.float32(0.5) + np.float32(sigma)
-        return np.clip(out, clip[0], clip[1]) if clip is not None else out
+        n = int(np.prod(shape))
+        for a, b in zip(in_addrs, out_addrs):
+            x = np.ctypeslib.as_array((ctypes.c_float * n).from_address(a))
+            y = np.ctypeslib.as_array((ctypes.c_float * n).from_address(b))
+            out = x * np.float32(0.5) + np.float32(sigma)
+            y[...] = np.clip(out, clip[0], clip[1]) if clip is not None else out
 
 
 def _worker(args):
@@ -85,6 +90,7 @@ def test_broker_protocol_coalesces_forked_workers(monkeypatch, tmp_path):
     monkeypatch.setenv("EXABM4D_DEVICE", "0")
     fake = _FakeContext()
     monkeypatch.setattr(_native, "context", lambda device=None: fake)
+    monkeypatch.setattr(_native, "new_context", lambda device=None: fake)
     broker._authkey(0, create=True)
     t = threading.Thread(target=broker.serve, kwargs=dict(device=0, idle=1.5, linger=0.01), daemon=True)
     t.start()
@@ -101,14 +107,66 @@ def test_broker_protocol_coalesces_forked_workers(monkeypatch, tmp_path):
     assert not os.path.exists(broker.socket_path(0))
 
 
+def test_batch_cap_cuts_the_clients_into_one_group_per_slot():
+    assert broker.batch_cap(16, 2) == 8 and broker.batch_cap(17, 2) == 9 and broker.batch_cap(256, 2) == 128
+    assert broker.batch_cap(1, 2) == 1 and broker.batch_cap(0, 2) == 1 and broker.batch_cap(5, 1) == 5
+
+
+class _OverlapContext(_FakeContext):
+    """Counts how many device calls are inside the 'device' at the same time."""
+    lock = threading.Lock()
+    inside = 0
+    most = 0
+
+    def denoise_f32_host_v(self, *a, **k):
+        with _OverlapContext.lock:
+            _OverlapContext.inside += 1
+            _OverlapContext.most = max(_OverlapContext.most, _OverlapContext.inside)
+        try:
+            super().denoise_f32_host_v(*a, **k)
+        finally:
+            with _OverlapContext.lock:
+                _OverlapContext.inside -= 1
+
+
+def test_two_calls_in_flight_and_one_slot(monkeypatch, tmp_path):
+    """slots=2: the clients are cut into two groups whose calls overlap (one group's workers do their host
+    work while the other group's call runs); slots=1 is the lockstep form.  Same answers either way."""
+    for slots, want_overlap in ((2, True), (1, False)):
+        d = tmp_path / f"s{slots}"
+        d.mkdir()
+        monkeypatch.setenv(broker.ENV_DIR, str(d))
+        monkeypatch.setenv("EXABM4D_DEVICE", "0")
+        _OverlapContext.most = 0
+        fake = _OverlapContext()
+        monkeypatch.setattr(_native, "context", lambda device=None: fake)
+        monkeypatch.setattr(_native, "new_context", lambda device=None: fake)
+        broker._authkey(0, create=True)
+        t = threading.Thread(target=broker.serve, kwargs=dict(device=0, idle=1.0, linger=0.01, slots=slots),
+                             daemon=True)
+        t.start()
+        for _ in range(200):
+            if os.path.exists(broker.socket_path(0)):
+                break
+            time.sleep(0.01)
+        with multiprocessing.get_context("fork").Pool(6) as pool:
+            assert all(pool.map(_worker, [(s, 6) for s in range(6)], chunksize=1))
+        t.join(timeout=10)
+        assert not t.is_alive()
+        assert sum(fake.batches) == 6 * 6 + 6 * 2
+        assert max(fake.batches) <= (6 if slots == 2 else 12)      # requests per call <= ceil(6 / slots), two volumes each at most
+        assert (_OverlapContext.most >= 2) == want_overlap
+
+
 def test_broker_reports_errors_instead_of_hanging(monkeypatch, tmp_path):
     monkeypatch.setenv(broker.ENV_DIR, str(tmp_path))
 
     class Failing:
-        def denoise_f32_host(self, *a, **k):
+        def denoise_f32_host_v(self, *a, **k):
             raise ValueError("sigma must be > 0")
 
     monkeypatch.setattr(_native, "context", lambda device=None: Failing())
+    monkeypatch.setattr(_native, "new_context", lambda device=None: Failing())
     broker._authkey(0, create=True)
     t = threading.Thread(target=broker.serve, kwargs=dict(device=0, idle=0.5, linger=0.0), daemon=True)
     t.start()

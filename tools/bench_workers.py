@@ -57,6 +57,9 @@ def pool_leg(n, workers, env):
         t0 = time.perf_counter()
         sums = list(pool.map(checksum, range(n), chunksize=1))
         dt = time.perf_counter() - t0
+    if env.get("EXABM4D_BROKER") == "1":
+        from aind_exaspim_image_compression import broker
+        print("broker stats:", broker.stats(0), file=sys.stderr, flush=True)
     return dt, sums
 
 
