@@ -258,26 +258,37 @@ def test_host_batch_of_scattered_volumes(ctx, oracle):
 
 
 def test_calls_queued_back_to_back_and_the_zeroing_stream(ctx, oracle):
-    """The 8-byte sums are zeroed on a second stream under block matching (option
-    ``zero_overlap``).  Calls queued without a synchronisation between them share the sums' memory: the
-    zeroing of call k + 1 must wait for the last reader of call k.  Same bits in line and overlapped."""
-    shape = (40, 44, 48)
-    vols = [synth_volume(shape, seed=s, as_u16=True)[0] for s in (61, 62, 63)]
-    want = [oracle.bm4d_u16(v, SIGMA, 37.0) for v in vols]
+    """The 8-byte sums of a large call (>= 2^25 voxels) are zeroed on a second stream under block matching
+    (option ``zero_overlap``).  Calls queued without a synchronisation between them share the
+    sums' memory: the zeroing of call k + 1 must wait for the last reader of call k.  Same bits in line and
+    overlapped, large and small calls mixed, and the oracle's (its CPU port: 34 M voxels)."""
+    big, small = (132, 504, 512), (40, 44, 48)
+    assert np.prod(big) >= 1 << 25 > np.prod(small)
+    vols = [np.tile(synth_volume((132, 126, 128), seed=61, as_u16=True)[0], (1, 4, 4)),
+            synth_volume(small, seed=62, as_u16=True)[0]]
+    vols.append(vols[0][::-1].copy())
+    want_small = oracle.bm4d_u16(vols[1], SIGMA, 37.0)
+    want_big = oracle.bm4d_u16(vols[0], SIGMA, 37.0, port=True)
     d_in = [ctx.to_device(v) for v in vols]
     d_out = [ctx.alloc(v.nbytes) for v in vols]
-    for overlap in (1, 0, 1):
+    got = {}
+    for overlap in (1, 0):
         ctx.set_option("zero_overlap", overlap)
         try:
             for d in d_out:
                 d.fill(0xEE)
             for i in range(3):
-                ctx.denoise_u16(d_in[i], d_out[i], shape, SIGMA, 37.0)
+                ctx.denoise_u16(d_in[i], d_out[i], vols[i].shape, SIGMA, 37.0)
             ctx.sync()
         finally:
             ctx.set_option("zero_overlap", 1)
-        for i in range(3):
-            np.testing.assert_array_equal(d_out[i].download(shape, np.uint16), want[i])
+        got[overlap] = [d_out[i].download(vols[i].shape, np.uint16) for i in range(3)]
+    for i in range(3):
+        np.testing.assert_array_equal(got[1][i], got[0][i])
+    np.testing.assert_array_equal(got[1][0], want_big)
+    np.testing.assert_array_equal(got[1][1], want_small)
+    for d in d_in + d_out:
+        d.free()
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 8), (8, 9, 12), (12, 8, 8), (9, 9, 9), (16, 8, 20),
