@@ -45,6 +45,10 @@ struct exabm4d_ctx {
     // memsets back on the context's stream.
     int zero_overlap = 1;
     bool zero_on_side = false;  // the last zero_begin() went to the second stream
+    // exabm4d_denoise_f32_host: large batches in double-buffered sub-batches ("host_pipeline" = 0: one piece)
+    int host_pipeline = 1;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[3] = {nullptr, nullptr, nullptr};
     hipStream_t side = nullptr;
     hipEvent_t side_ev[2] = {nullptr, nullptr};     // [0] main -> side: the sums' last reader is done; [1] side -> main: zeroed
     unsigned* status_host = nullptr;   // one pinned, device-visible word: bit 0 = a carry wait of block matching ran out
@@ -161,6 +165,7 @@ static int ensure_scratch(exabm4d_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->scratch_bytes) return EXABM4D_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->side) HIP_TRY(ctx, hipStreamSynchronize(ctx->side));   // (memsets of a call that failed half way)
+    if (ctx->copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
@@ -312,6 +317,12 @@ int exabm4d_destroy(exabm4d_ctx* ctx) {
     }
     for (int i = 0; i < 2; i++)
         if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (int i = 0; i < 3; i++)
+        if (ctx->copy_ev[i]) (void)hipEventDestroy(ctx->copy_ev[i]);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->status_host) (void)hipHostFree(ctx->status_host);
     if (ctx->red) (void)hipFree(ctx->red);
@@ -392,6 +403,10 @@ int exabm4d_set_option(exabm4d_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "bm_carry") == 0) {           // block matching: carry between the tiles of a column (0 off, 1 automatic, 2 forced)
         if (value < 0 || value > 2) return fail(ctx, EXABM4D_ERR_INVALID, "bm_carry must be 0, 1 or 2");
         ctx->bm.carry = value;
+        return EXABM4D_OK;
+    }
+    if (std::strcmp(name, "host_pipeline") == 0) {      // exabm4d_denoise_f32_host: large batches in overlapped sub-batches
+        ctx->host_pipeline = value ? 1 : 0;
         return EXABM4D_OK;
     }
     if (std::strcmp(name, "zero_overlap") == 0) {       // the sums' memsets under block matching (second stream) or in line
@@ -1125,6 +1140,66 @@ int exabm4d_denoise_chunked_u16_host(exabm4d_ctx* ctx, const uint16_t* in, uint1
     return check_async_status(ctx);
 }
 
+// A large batch goes through the device in sub-batches of about 2^26 voxels, double-buffered: while sub-batch k
+// is computed, the results of k - 1 come down and the input of k + 1 goes up on a copy stream of the context's
+// (the host side of a pageable copy blocks, which is all the ordering this thread needs; the device side is
+// ordered by events).  Every volume carries its own fixed-point unit, so the cut changes no bit.  1000 patches
+// of 64^3, host to host: 245 -> see DESIGN.md 8a; the scratch is that of one sub-batch, not of the batch.
+static constexpr size_t HOST_SUB_VOXELS = (size_t)1 << 26;
+static int denoise_f32_host_pipelined(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
+                                      int batch, int sub, float sigma, const exabm4d_params* p, int stages,
+                                      float clip_lo, float clip_hi) {
+    VolGeom g;
+    int rc = make_geom(ctx, nz, ny, nx, sub, g);
+    if (rc) return rc;
+    const size_t nv = (size_t)g.nvox, nsubvox = nv * (size_t)sub;
+    const size_t base = pipe_bytes(ctx->bm, nz, ny, nx, sub, stages);
+    const size_t bufbytes = align256(nsubvox * sizeof(float)) + GUARD_BYTES;
+    rc = ensure_scratch(ctx, base + 2 * bufbytes);
+    if (rc) return rc;
+    if (!ctx->copy_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 3; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->copy_ev[i], hipEventDisableTiming));
+    }
+    char* scratch = static_cast<char*>(ctx->scratch);
+    float* buf[2] = {reinterpret_cast<float*>(scratch + base), reinterpret_cast<float*>(scratch + base + bufbytes)};
+    hipStream_t cs = ctx->copy_stream, s = ctx->stream;
+    const int nsub = (batch + sub - 1) / sub;
+    auto count_of = [&](int k) { return std::min(sub, batch - k * sub); };
+    // the buffers' last users were earlier calls on the compute stream
+    HIP_TRY(ctx, hipEventRecord(ctx->copy_ev[2], s));
+    HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->copy_ev[2], 0));
+    HIP_TRY(ctx, hipMemcpyAsync(buf[0], in, nv * count_of(0) * sizeof(float), hipMemcpyHostToDevice, cs));
+    for (int k = 0; k < nsub; k++) {
+        const int cnt = count_of(k);
+        VolGeom gk = g;
+        if (cnt != sub) {
+            rc = make_geom(ctx, nz, ny, nx, cnt, gk);
+            if (rc) return rc;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->copy_ev[2], cs));                     // input k is up
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->copy_ev[2], 0));
+        rc = run_pipeline(ctx, buf[k & 1], buf[k & 1], nullptr, gk, cnt, sigma, p, stages, clip_lo, clip_hi, 0.0f,
+                          scratch, 1, EXABM4D_DATA_EXP_AUTO);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(ctx->copy_ev[k & 1], s));                  // result k is ready
+        if (k >= 1) {                                                          // result k - 1 down, under compute k
+            HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->copy_ev[(k - 1) & 1], 0));
+            HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)(k - 1) * nsubvox, buf[(k - 1) & 1],
+                                        nv * count_of(k - 1) * sizeof(float), hipMemcpyDeviceToHost, cs));
+        }
+        if (k + 1 < nsub)                                                      // input k + 1 up, into the buffer just emptied
+            HIP_TRY(ctx, hipMemcpyAsync(buf[(k + 1) & 1], in + (size_t)(k + 1) * nsubvox,
+                                        nv * count_of(k + 1) * sizeof(float), hipMemcpyHostToDevice, cs));
+    }
+    HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->copy_ev[(nsub - 1) & 1], 0));
+    HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)(nsub - 1) * nsubvox, buf[(nsub - 1) & 1],
+                                nv * count_of(nsub - 1) * sizeof(float), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(ctx, hipStreamSynchronize(cs));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return check_async_status(ctx);
+}
+
 int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int nz, int ny, int nx,
                              int batch, float sigma, const exabm4d_params* p, int stages,
                              float clip_lo, float clip_hi) {
@@ -1132,6 +1207,15 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     int rc = pipeline_checks(ctx, in, out, nz, ny, nx, batch, sigma, p, stages, g);
     if (rc) return rc;
     const size_t n = (size_t)g.nvox * (size_t)batch;
+    // Large batches of volumes: sub-batches with the copies under the kernels.  Not in place (a repeated run
+    // must find its input), not while a debug option wants to see one launch.
+    const size_t per = std::max<size_t>(1, HOST_SUB_VOXELS / (size_t)g.nvox);
+    if (ctx->host_pipeline && in != out && batch >= 2 && (size_t)batch >= 2 * per && per <= 65535) {
+        rc = denoise_f32_host_pipelined(ctx, in, out, nz, ny, nx, batch, (int)per, sigma, p, stages, clip_lo,
+                                        clip_hi);
+        if (rc == EXABM4D_OK || ctx->bm.carry != 0) return rc;
+        // the carry's wait ran out somewhere (it is off now): once more below, in one piece
+    }
     // This call owns its input and synchronises, so a run whose carry wait ran out (check_async_status) is
     // simply repeated without the carry: the caller of bm4d(raw, sigma) sees a result, never a hang or a retry.
     for (int attempt = 0;; attempt++) {
@@ -1144,10 +1228,16 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
         rc = run_pipeline(ctx, vol, vol, nullptr, g, batch, sigma, p, stages, clip_lo, clip_hi, 0.0f,
                           scratch, 1, EXABM4D_DATA_EXP_AUTO);
         if (rc) return rc;
-        HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        // (out may be in: the result goes to the host only once the run is known to be good)
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         rc = check_async_status(ctx);
-        if (rc == EXABM4D_OK || attempt == 1 || ctx->bm.carry != 0) return rc;
+        if (rc != EXABM4D_OK) {
+            if (attempt == 1 || ctx->bm.carry != 0) return rc;
+            continue;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(out, vol, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return EXABM4D_OK;
     }
 }
 

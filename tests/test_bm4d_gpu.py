@@ -257,6 +257,24 @@ def test_host_batch_of_scattered_volumes(ctx, oracle):
         ctx.denoise_f32_host_v(addrs[:2], addrs[:1], shape, SIGMA)
 
 
+def test_large_host_batch_in_overlapped_sub_batches(ctx, oracle):
+    """exabm4d_denoise_f32_host cuts a batch of >= 2^27 voxels into sub-batches of 2^26 and copies under the
+    kernels (option ``host_pipeline``): 520 patches of 64^3 = 256 + 256 + 8.  Same bits as the call in one
+    piece and as the oracle (spot checks: first, a middle one, the ragged tail)."""
+    base = np.stack([synth_volume((64, 64, 64), seed=80 + i)[0] for i in range(8)])
+    raw = np.concatenate([base + np.float32(3 * k) for k in range(65)])
+    assert raw.shape[0] == 520
+    got = ctx.denoise_f32_host(raw, SIGMA, clip=(0.0, 65535.0))
+    ctx.set_option("host_pipeline", 0)
+    try:
+        one = ctx.denoise_f32_host(raw, SIGMA, clip=(0.0, 65535.0))
+    finally:
+        ctx.set_option("host_pipeline", 1)
+    np.testing.assert_array_equal(got, one)
+    for i in (0, 300, 519):
+        np.testing.assert_array_equal(got[i], np.clip(oracle.bm4d(raw[i], SIGMA), 0, 65535))
+
+
 def test_calls_queued_back_to_back_and_the_zeroing_stream(ctx, oracle):
     """The 8-byte sums of a large call (>= 2^25 voxels) are zeroed on a second stream under block matching
     (option ``zero_overlap``).  Calls queued without a synchronisation between them share the

@@ -19,7 +19,9 @@ def call(out):
     assert rc == 0
     return (time.perf_counter() - t0) * 1e3
 denoise_patches(raw[:32], 24.0)
-for rep in range(2):
+for rep in range(4):
+    ctx.set_option("host_pipeline", rep & 1)
+    print("host_pipeline", rep & 1)
     t0 = time.perf_counter(); out = denoise_patches(raw, 24.0); dt = (time.perf_counter() - t0) * 1e3
     print(f"denoise_patches({n} x 64^3): {dt:7.1f} ms", flush=True)
     fresh = np.empty_like(raw)
