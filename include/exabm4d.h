@@ -129,7 +129,8 @@ int exabm4d_default_params(exabm4d_params* p);
  * instead of hanging, the next synchronising call (exabm4d_sync, exabm4d_memcpy_d2h, *_host, ...) returns
  * EXABM4D_ERR_HIP, and the carry is off for that context from then on (exabm4d_denoise_f32_host repeats its
  * run without the carry by itself).  "bm_carry_fault" = 1 (debug) makes every such wait count as run out; "bm_xcd_mode" = 0 | 1 | n (default 2): workgroup order of
- * block matching; "zero_overlap" = 0 | 1 (default 1): the 8-byte sums are zeroed on a second
+ * block matching; "host_pipeline" = 0 | 1 (default 1): exabm4d_denoise_f32_host cuts batches of >= 2^27 voxels
+ * into sub-batches and copies under the kernels; "zero_overlap" = 0 | 1 (default 1): the 8-byte sums are zeroed on a second
  * stream of the context's, under the block matching that precedes each stage kernel, instead of in line
  * (DESIGN.md 5.3); "stage_strip" = 0 | n (default 3): tile-column order of the stage
  * kernels (0 = raster, n = strips of n tile rows; the same results, bit for bit: the sums are integers).
