@@ -106,6 +106,7 @@ SIGNATURES = {
     "exabm4d_stage_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, c_vp, c_vp]),
     "exabm4d_normalize_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F, _F]),
     "exabm4d_counts_from_u16_dev": (_I, [_CTX, c_vp, c_vp, _SZ, _F]),
+    "exabm4d_round_counts_f32_dev": (_I, [_CTX, c_vp, c_vp, _SZ, _F]),
     "exabm4d_normalize_u16_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _SZ, _F]),
     "exabm4d_denoise_f32_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_denoise_u16_dev": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _F, _PP, _I]),
@@ -398,6 +399,11 @@ class Context:
     def counts_from_u16(self, src, dst, n, offset):
         """dst (fp32) = (float)src - offset: read_counts, data_handling.py:337-354"""
         self._check(lib().exabm4d_counts_from_u16_dev(self.handle, _ptr(src), _ptr(dst), n, offset))
+
+    def round_counts(self, src, dst, n, offset):
+        """dst (fp32) = (float)rint(clamp(src + offset, 0, 65535)) - offset: what stage 2 of the uint16
+        pipelines matches on"""
+        self._check(lib().exabm4d_round_counts_f32_dev(self.handle, _ptr(src), _ptr(dst), n, offset))
 
     def normalize_u16(self, num, den, out, n, offset):
         """out (uint16) = rint(clamp(num / den + offset, 0, 65535))"""

@@ -254,7 +254,10 @@ class SlabDenoiser:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device)
             ctx.set_stream(stream.cuda_stream)
-            ctx.blockmatch(basic, self.shape, self.sigma, self.params.c_match_wie, self.keys,
+            # the uint16 pipelines match stage 2 on the basic estimate rounded to counts;
+            # self.den is free until the stage call writes it
+            ctx.round_counts(basic, self.den, n, float(offset))
+            ctx.blockmatch(self.den, self.shape, self.sigma, self.params.c_match_wie, self.keys,
                            self.params)
             ctx.stage(noisy, basic, self.keys, self.shape, self.sigma, self.num, self.den, self.params,
                       data_exp=self.u16_exp)
@@ -427,7 +430,8 @@ def denoise_slab_u16_native(ctx, comm, d_raw, plan, shape, sigma, offset, params
         ctx.stage(d_noisy, None, d_keys, shape, sigma, d_num, d_den, p, data_exp=_native.DATA_EXP_U16)
         ctx.normalize(d_num, d_den, d_basic, n)
         exchange_halo_native(comm, d_basic, plan, 4 * shape[1] * shape[2])
-        ctx.blockmatch(d_basic, shape, sigma, p.c_match_wie, d_keys, p)
+        ctx.round_counts(d_basic, d_den, n, float(offset))          # stage 2 matches on counts
+        ctx.blockmatch(d_den, shape, sigma, p.c_match_wie, d_keys, p)
         ctx.stage(d_noisy, d_basic, d_keys, shape, sigma, d_num, d_den, p, data_exp=_native.DATA_EXP_U16)
         ctx.normalize_u16(d_num, d_den, d_out, n, float(offset))
         return d_out

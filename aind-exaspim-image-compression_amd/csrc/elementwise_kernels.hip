@@ -154,6 +154,38 @@ struct OpNormalizeU16 {
         st8(out + i, q);
     }
 };
+// what stage 2 of the uint16 pipelines matches on -- the basic estimate as the counts a uint16
+// caller would see.  As fp32 (counts - offset: the float kernel's input) or as counts XOR 0x8000 (the integer
+// kernel's); the Wiener filter itself keeps the unrounded estimate.
+struct OpRoundCountsF32 {
+    const float* in;
+    float* out;
+    float offset;
+    __device__ void one(size_t i) const { out[i] = (float)quantise_u16(in[i] + offset, 65535.0f) - offset; }
+    __device__ void eight(size_t i) const {
+        float v[8];
+        ld8(in + i, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (float)quantise_u16(v[k] + offset, 65535.0f) - offset;
+        st8(out + i, v);
+    }
+};
+struct OpRoundCountsU16 {
+    const float* in;
+    uint16_t* out16;
+    float offset;
+    __device__ void one(size_t i) const {
+        out16[i] = (uint16_t)(quantise_u16(in[i] + offset, 65535.0f) ^ 0x8000u);
+    }
+    __device__ void eight(size_t i) const {
+        float v[8];
+        uint16_t q[8];
+        ld8(in + i, v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = (uint16_t)(quantise_u16(v[k] + offset, 65535.0f) ^ 0x8000u);
+        st8(out16 + i, q);
+    }
+};
 template <typename TIn>
 struct OpTfForward {
     TfDev t;
@@ -748,6 +780,13 @@ hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, floa
         return launch_stream(OpCountsFromU16Both{in, out, out16, offset}, n,
                              aligned16(in, out) && ((uintptr_t)out16 & 15) == 0, s);
     return launch_stream(OpCountsFromU16{in, out, offset}, n, aligned16(in, out), s);
+}
+hipError_t launch_round_counts(const float* in, float* out_f32, uint16_t* out_u16x, size_t n, float offset,
+                               hipStream_t s) {
+    if (out_u16x)
+        return launch_stream(OpRoundCountsU16{in, out_u16x, offset}, n,
+                             aligned16(in, in) && ((uintptr_t)out_u16x & 15) == 0, s);
+    return launch_stream(OpRoundCountsF32{in, out_f32, offset}, n, aligned16(in, out_f32), s);
 }
 hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,
                                 float offset, hipStream_t s) {

@@ -711,6 +711,13 @@ int exabm4d_counts_from_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, float* out
     return EXABM4D_OK;
 }
 
+int exabm4d_round_counts_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, size_t n, float offset) {
+    if (!ctx || !in || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_round_counts(in, out, nullptr, n, offset, ctx->stream));
+    return EXABM4D_OK;
+}
+
 int exabm4d_normalize_u16_dev(exabm4d_ctx* ctx, const float* num, const float* den, uint16_t* out,
                               size_t n, float offset) {
     if (!ctx || !num || !den || !out) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
@@ -774,7 +781,8 @@ static int zero_join(exabm4d_ctx* ctx, hipStream_t s) {
 static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, uint16_t* out_u16,
                         const VolGeom& g, int batch, float sigma, const exabm4d_params* p,
                         int stages, float clip_lo, float clip_hi, float u16_offset, char* scratch,
-                        int noisy_guarded, int data_exp, const uint16_t* noisy16 = nullptr) {
+                        int noisy_guarded, int data_exp, const uint16_t* noisy16 = nullptr,
+                        int match_counts = 0, float match_offset = 0.0f) {
     // noisy16: the same volume as uint16 counts XOR 0x8000, guarded like `noisy`, when the caller
     // is a uint16 pipeline: stage-1 matching then runs in integer arithmetic (bm_tile16_kernel),
     // provided its tables equal the float kernel's -- admission bound below 2^24, even row length
@@ -782,6 +790,10 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     // ensure_scratch and bm_tile_kernel); a caller's own device buffer is not assumed to.
     // data_exp: E of the numerator's unit: 17 from the uint16 entry points,
     // EXABM4D_DATA_EXP_AUTO (from every volume's largest |v|) from the fp32 ones.
+    // match_counts (the uint16 entry points): stage 2 matches on the basic estimate ROUNDED TO
+    // COUNTS -- rint(clamp(basic + match_offset, 0, 65535)) -- so that it can run in integer arithmetic like
+    // stage 1 (noisy16's memory is free by then and takes the rounded volume); where the integer kernel does
+    // not apply, the float kernel runs on the same counts as fp32 (in `tmp`, dead between the stages).
     const size_t n = (size_t)g.nvox * (size_t)batch;
     const BmPlan plan = bm_plan(g, batch, ctx->bm);           // one plan for both matching launches
     const PipeLayout L = pipe_layout(n, (size_t)g.nref * (size_t)batch, batch, stages, plan.carry_bytes);
@@ -843,8 +855,26 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_BLOCKMATCH_WIE);
-            HIP_TRY(ctx, launch_blockmatch(basic, g, batch, keymax_of(sigma, p->c_match_wie), keys,
-                                           s, ctx->force_generic_bm, 1, nullptr, plan, scratch + L.carry,
+            const float* match_on = basic;
+            const uint16_t* match16 = nullptr;
+            int match_guarded = 1;
+            if (match_counts) {
+                const double tau512 = (double)p->c_match_wie * (double)sigma * (double)sigma * 512.0;
+                const bool use16 = noisy16 && ctx->bm_int && tau512 < 16777216.0 && (g.nx % 2) == 0 &&
+                                   offset_exact_in_fp32(match_offset) &&
+                                   guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
+                if (use16) {
+                    uint16_t* m16 = const_cast<uint16_t*>(noisy16);      // our own scratch; stage 1 is done with it
+                    HIP_TRY(ctx, launch_round_counts(basic, nullptr, m16, n, match_offset, s));
+                    match16 = m16;
+                } else {
+                    HIP_TRY(ctx, launch_round_counts(basic, tmp, nullptr, n, match_offset, s));
+                    match_on = tmp;
+                    match_guarded = guarded_region_ok(ctx, tmp, n * sizeof(float)) ? 1 : 0;
+                }
+            }
+            HIP_TRY(ctx, launch_blockmatch(match_on, g, batch, keymax_of(sigma, p->c_match_wie), keys,
+                                           s, ctx->force_generic_bm, match_guarded, match16, plan, scratch + L.carry,
                                            ctx->status_dev));
         }
         {
@@ -911,7 +941,7 @@ int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out,
         HIP_TRY(ctx, launch_counts_from_u16(in, noisy, n, offset, ctx->stream, noisy16));
     }
     return run_pipeline(ctx, noisy, nullptr, out, g, batch, sigma, p, stages, 0.0f, 0.0f, offset,
-                        scratch, 1, EXABM4D_DATA_EXP_U16, noisy16);
+                        scratch, 1, EXABM4D_DATA_EXP_U16, noisy16, 1, offset);
 }
 
 // Chunk-local mode: every chunk (core + halo, the halo cut off where the buffer ends) is denoised
@@ -975,7 +1005,8 @@ int exabm4d_denoise_chunked_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16
                     uint16_t* vol16 = reinterpret_cast<uint16_t*>(scratch + base + fbytes + GUARD_BYTES);
                     HIP_TRY(ctx, launch_chunk_gather(in, cb, offset, vol, ctx->stream, vol16));
                     rc = run_pipeline(ctx, vol, vol, nullptr, g, count, sigma, p, stages, 1.0f, 0.0f, 0.0f,
-                                      scratch, 1, EXABM4D_DATA_EXP_U16, offset_exact_in_fp32(offset) ? vol16 : nullptr);
+                                      scratch, 1, EXABM4D_DATA_EXP_U16, offset_exact_in_fp32(offset) ? vol16 : nullptr,
+                                      1, offset);
                     if (rc) return rc;
                     HIP_TRY(ctx, launch_chunk_scatter(vol, cb, offset, out, ctx->stream));
                 }

@@ -20,6 +20,9 @@ hipError_t launch_normalize(const float* num, const float* den, float* out, size
                             float hi, hipStream_t s);
 hipError_t launch_counts_from_u16(const uint16_t* in, float* out, size_t n, float offset,
                                   hipStream_t s, uint16_t* out16 = nullptr);
+// out_u16x != NULL: counts XOR 0x8000 (integer block matching); else out_f32 = counts - offset.  DESIGN.md 3.9.
+hipError_t launch_round_counts(const float* in, float* out_f32, uint16_t* out_u16x, size_t n, float offset,
+                               hipStream_t s);
 hipError_t launch_normalize_u16(const float* num, const float* den, uint16_t* out, size_t n,
                                 float offset, hipStream_t s);
 hipError_t launch_tf_forward_u16(const TfDev& t, const uint16_t* in, float* out, size_t n,

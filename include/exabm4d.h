@@ -234,6 +234,10 @@ int exabm4d_counts_from_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, float* out
  * the cast of IntensityTransform.inverse, transforms.py:168-171). */
 int exabm4d_normalize_u16_dev(exabm4d_ctx* ctx, const float* num, const float* den, uint16_t* out,
                               size_t n, float offset);
+/* What stage 2 of the uint16 pipelines matches on: the basic estimate as the counts a uint16
+ * caller would see, out = (float)rint(clamp(in + offset, 0, 65535)) - offset; in / out may alias.  For callers
+ * that run the stages themselves: exabm4d_blockmatch_dev on `out`, exabm4d_stage_dev on the unrounded `in`. */
+int exabm4d_round_counts_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, size_t n, float offset);
 
 /* ---- BM4D whole pipeline ------------------------------------------------------------------- */
 /* stages: 1 = hard-threshold only, 2 = hard-threshold + Wiener.  in/out may alias.

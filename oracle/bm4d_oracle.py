@@ -66,6 +66,10 @@ def lib():
                                c_f, c_f]
         L.orc_bm4d_e.argtypes = L.orc_bm4d.argtypes + [c_int]
         L.orc_bm4d_e.restype = None
+        L.orc_bm4d_m.argtypes = L.orc_bm4d.argtypes + [c_int, c_int, c_f]
+        L.orc_bm4d_m.restype = None
+        L.orc_round_counts.argtypes = [f32p, f32p, c_sz, c_f]
+        L.orc_round_counts.restype = None
         L.orc_bm4d_u16.argtypes = [u16p, u16p, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_f, c_d,
                                    c_int]
         L.orc_dctq_forward.argtypes = [u16p, c_int, c_int, c_int, c_f, i32p]
@@ -212,9 +216,20 @@ def normalize(num, den, clip=None):
     return out
 
 
-def bm4d(vol, sigma, stages=2, clip=None, data_exp=None, **kw):
+def round_counts(vol, offset):
+    """What stage 2 of the uint16 form matches on: fl(rint(clamp(v + offset, 0, 65535))) -
+    offset, element by element."""
+    vol = _f32(vol)
+    out = np.empty_like(vol)
+    lib().orc_round_counts(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), vol.size, float(offset))
+    return out
+
+
+def bm4d(vol, sigma, stages=2, clip=None, data_exp=None, match_counts_offset=None, **kw):
     """Whole two-stage pipeline on one fp32 volume.  ``data_exp``: E of DESIGN.md 3.8 (None: from the
-    volume, as the fp32 entry points do; 17 reproduces the uint16 entry points)."""
+    volume, as the fp32 entry points do; 17 reproduces the uint16 entry points).  ``match_counts_offset``:
+    stage 2 matches on ``round_counts(basic, offset)`` as the uint16 entry points do (None: on the basic
+    estimate itself, the fp32 entry points)."""
     p = {**DEFAULTS, **kw}
     vol = _f32(vol)
     nz, ny, nx = vol.shape
@@ -222,10 +237,12 @@ def bm4d(vol, sigma, stages=2, clip=None, data_exp=None, **kw):
         raise ValueError("fp32 volume outside the working range of DESIGN.md 3.8 (|v| >= 2^56, inf or NaN)")
     out = np.empty_like(vol)
     lo, hi = (1.0, 0.0) if clip is None else clip
-    lib().orc_bm4d_e(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), nz, ny, nx, float(sigma),
+    lib().orc_bm4d_m(_p(vol, ctypes.c_float), _p(out, ctypes.c_float), nz, ny, nx, float(sigma),
                      float(p["lambda_ht"]), float(p["c_match_ht"]), float(p["c_match_wie"]),
                      float(p["kaiser_beta"]), int(stages), float(lo), float(hi),
-                     AUTO_EXP if data_exp is None else int(data_exp))
+                     AUTO_EXP if data_exp is None else int(data_exp),
+                     0 if match_counts_offset is None else 1,
+                     0.0 if match_counts_offset is None else float(match_counts_offset))
     return out
 
 

@@ -456,7 +456,7 @@ void cpu_stage(const float* noisy, const float* basic, const uint32_t* keys, int
 
 static void cpu_bm4d_e(const float* in, float* out, int nz, int ny, int nx, float sigma, float lambda_ht,
                        float c_match_ht, float c_match_wie, double beta, int stages, float clip_lo,
-                       float clip_hi, int data_exp) {
+                       float clip_hi, int data_exp, int match_counts, float offset) {
     const size_t n = (size_t)nz * ny * nx;
     const long nref = (long)orc_grid_count(nz) * orc_grid_count(ny) * orc_grid_count(nx);
     uint32_t* keys = malloc(sizeof(uint32_t) * (size_t)nref * MAXG);
@@ -470,7 +470,19 @@ static void cpu_bm4d_e(const float* in, float* out, int nz, int ny, int nx, floa
     } else {
         float* basic = malloc(sizeof(float) * n);
         orc_normalize(num, den, basic, n, 1.0f, 0.0f);
-        cpu_blockmatch(basic, nz, ny, nx, sigma, c_match_wie, keys);
+        if (match_counts) {                    /* the uint16 form: stage 2 matches on counts */
+            float* m = malloc(sizeof(float) * n);
+#pragma omp parallel for schedule(static)
+            for (size_t i = 0; i < n; i++) {
+                float v = basic[i] + offset;
+                v = v < 0.0f ? 0.0f : v;
+                v = v > 65535.0f ? 65535.0f : v;
+                m[i] = rintf(v) - offset;
+            }
+            cpu_blockmatch(m, nz, ny, nx, sigma, c_match_wie, keys);
+            free(m);
+        } else
+            cpu_blockmatch(basic, nz, ny, nx, sigma, c_match_wie, keys);
         cpu_stage(in, basic, keys, nz, ny, nx, sigma, lambda_ht, beta, data_exp, num, den);
         orc_normalize(num, den, out, n, clip_lo, clip_hi);
         free(basic);
@@ -482,7 +494,7 @@ static void cpu_bm4d_e(const float* in, float* out, int nz, int ny, int nx, floa
 void cpu_bm4d(const float* in, float* out, int nz, int ny, int nx, float sigma, float lambda_ht,
               float c_match_ht, float c_match_wie, double beta, int stages, float clip_lo, float clip_hi) {
     cpu_bm4d_e(in, out, nz, ny, nx, sigma, lambda_ht, c_match_ht, c_match_wie, beta, stages, clip_lo, clip_hi,
-               INT32_MIN);
+               INT32_MIN, 0, 0.0f);
 }
 
 void cpu_bm4d_u16(const uint16_t* in, uint16_t* out, int nz, int ny, int nx, float sigma, float offset,
@@ -492,7 +504,7 @@ void cpu_bm4d_u16(const uint16_t* in, uint16_t* out, int nz, int ny, int nx, flo
     float* g = malloc(sizeof(float) * n);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) f[i] = (float)in[i] - offset;
-    cpu_bm4d_e(f, g, nz, ny, nx, sigma, lambda_ht, c_match_ht, c_match_wie, beta, stages, 1.0f, 0.0f, 17);
+    cpu_bm4d_e(f, g, nz, ny, nx, sigma, lambda_ht, c_match_ht, c_match_wie, beta, stages, 1.0f, 0.0f, 17, 1, offset);
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < n; i++) {
         float v = g[i] + offset;

@@ -120,10 +120,27 @@ def test_psnr_gain_and_stage_order(oracle):
 
 def test_u16_pipeline_equals_float_pipeline(oracle):
     vol, _ = synth_volume((24, 28, 32), seed=8, as_u16=True)
-    # the uint16 form fixes the numerator's unit (E = 17) instead of reading it off the data
-    f = oracle.bm4d(vol.astype(np.float32) - np.float32(37.0), SIGMA, data_exp=oracle.U16_DATA_EXP)
+    # the uint16 form fixes the numerator's unit (E = 17) instead of reading it off the data, and
+    # matches stage 2 on the basic estimate rounded to counts
+    f = oracle.bm4d(vol.astype(np.float32) - np.float32(37.0), SIGMA, data_exp=oracle.U16_DATA_EXP,
+                    match_counts_offset=37.0)
     want = np.rint(np.clip(f + np.float32(37.0), 0, 65535)).astype(np.uint16)
     np.testing.assert_array_equal(oracle.bm4d_u16(vol, SIGMA, 37.0), want)
+    np.testing.assert_array_equal(oracle.bm4d_u16(vol, SIGMA, 37.0, port=True), want)
+    # ... which is the pipeline spelled out: stage 1, round, match on the rounded volume, filter with the unrounded one
+    x = vol.astype(np.float32) - np.float32(37.0)
+    E = oracle.U16_DATA_EXP
+    basic = oracle.bm4d(x, SIGMA, stages=1, data_exp=E)
+    m = oracle.round_counts(basic, 37.0)
+    np.testing.assert_array_equal(m, np.rint(np.clip(basic + np.float32(37.0), 0, 65535)).astype(np.float32)
+                                  - np.float32(37.0))
+    assert np.abs(m - basic).max() <= 0.5 + 1e-3
+    keys = oracle.blockmatch(m, SIGMA, oracle.DEFAULTS["c_match_wie"])
+    num, den = oracle.stage(x, keys, SIGMA, basic=basic, data_exp=E)
+    np.testing.assert_array_equal(oracle.normalize(num, den), f)
+    # the fp32 form matches on the basic estimate itself: a different (equally good) set of groups
+    g = oracle.bm4d(x, SIGMA, data_exp=E)
+    assert not np.array_equal(g, f) and np.abs(g - f).max() < 0.25 * SIGMA
 
 
 def test_crop_invariance(oracle):

@@ -57,8 +57,19 @@ def test_the_volumes_that_used_to_differ_are_bit_exact_now(ctx, oracle, name, si
         for b in (d_f, d_k, d_num, d_den, d_est):
             b.free()
     np.testing.assert_array_equal(basic_g, basic_o)
-    # ... hence the same stage-2 tables (the step that used to diverge) ...
+    # ... hence the same stage-2 tables (the step that used to diverge), on the estimate itself (fp32 form) and
+    # on its counts (uint16 form) ...
     np.testing.assert_array_equal(_keys(ctx, basic_g, sigma, 0.6), oracle.blockmatch(basic_o, sigma, 0.6))
+    counts_o = oracle.round_counts(basic_o, offset)
+    d_b = ctx.to_device(basic_g)
+    try:
+        ctx.round_counts(d_b, d_b, n, float(offset))
+        ctx.sync()
+        counts_g = d_b.download(shape, np.float32)
+    finally:
+        d_b.free()
+    np.testing.assert_array_equal(counts_g, counts_o)
+    np.testing.assert_array_equal(_keys(ctx, counts_g, sigma, 0.6), oracle.blockmatch(counts_o, sigma, 0.6))
     # ... and the same uint16 volume, launch after launch
     d_u, d_o = ctx.to_device(vol), ctx.alloc(vol.nbytes)
     try:
