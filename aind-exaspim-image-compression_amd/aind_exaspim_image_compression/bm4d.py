@@ -170,7 +170,8 @@ def denoise_patches(raw, sigma, max_count=65535.0, profile=None, device=None, de
 def denoise_volume(vol_u16, sigma, offset=0.0, profile=None, stages=2, device=None):
     """uint16 volume -> uint16 volume: ``(float)v - offset`` -> BM4D -> ``+ offset`` -> clip to
     [0, 65535] -> rint -> uint16, entirely on the device (read_counts + bm4d + clip + the
-    rint/uint16 cast of IntensityTransform.inverse)."""
+    rint/uint16 cast of IntensityTransform.inverse).  The uint16 form matches its second stage on the basic
+    estimate rounded to counts: both matching passes are 16-bit integer work."""
     vol = np.ascontiguousarray(vol_u16, dtype=np.uint16)
     if vol.ndim != 3:
         raise ValueError("denoise_volume expects a 3-D uint16 volume")

@@ -59,7 +59,7 @@ ALGO_BYTES_PER_VOXEL = {
     "blockmatch_ht": 2 + 1,          # stage-1 matching reads the uint16 planes (integer kernel)
     "stage_ht": 1 + 4 + 8,
     "normalize_basic": 8 + 4,
-    "blockmatch_wie": 4 + 1,
+    "blockmatch_wie": (4 + 2) + (2 + 1),   # the basic estimate rounded to counts, then the integer kernel
     "stage_wie": 1 + 4 + 4 + 8,
     "normalize_out": 8 + 2,
     # encode legs: volume / indices read once + the packed streams written (measured per run)

@@ -252,7 +252,11 @@ int exabm4d_denoise_f32_dev(exabm4d_ctx* ctx, const float* in, float* out, int n
 /* uint16 in -> (float)in - offset -> BM4D -> + offset -> clamp [0,65535] -> rint -> uint16.
  * (read_counts + bm4d + clip + the rint/uint16 cast of IntensityTransform.inverse.)  |offset| <= 65536.
  * The result is a deterministic function of the input: two calls, the chunked / streamed forms on
- * identical padded chunks and the oracle give the same uint16 values. */
+ * identical padded chunks and the oracle give the same uint16 values.
+ * The uint16 forms (this, the chunk-local ones) match stage 2 on the basic estimate ROUNDED TO COUNTS
+ * (both matching passes run in 16-bit integer arithmetic); the fp32 forms match on the estimate
+ * itself.  rint(clamp(exabm4d_denoise_f32_dev(in - offset) + offset)) is therefore a different -- equally
+ * good -- result than this call's on a few per cent of the voxels. */
 int exabm4d_denoise_u16_dev(exabm4d_ctx* ctx, const uint16_t* in, uint16_t* out, int nz, int ny,
                             int nx, int batch, float sigma, float offset, const exabm4d_params* p,
                             int stages);
