@@ -867,7 +867,11 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
                     uint16_t* m16 = const_cast<uint16_t*>(noisy16);      // our own scratch; stage 1 is done with it
                     HIP_TRY(ctx, launch_round_counts(basic, nullptr, m16, n, match_offset, s));
                     match16 = m16;
-                } else {
+                }
+                // reference blocks at clamped grid positions (an extent - 8 that is no multiple of 4) go through
+                // the one-wave kernel, which reads fp32: it needs the same counts as fp32
+                const bool generic_too = ctx->force_generic_bm || g.gz != g.az || g.gy != g.ay || g.gx != g.ax;
+                if (!use16 || generic_too) {
                     HIP_TRY(ctx, launch_round_counts(basic, tmp, nullptr, n, match_offset, s));
                     match_on = tmp;
                     match_guarded = guarded_region_ok(ctx, tmp, n * sizeof(float)) ? 1 : 0;

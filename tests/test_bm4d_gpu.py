@@ -309,6 +309,35 @@ def test_calls_queued_back_to_back_and_the_zeroing_stream(ctx, oracle):
         d.free()
 
 
+@pytest.mark.parametrize("shape,offset", [((29, 37, 42), 37.0), ((45, 9, 68), 37.0), ((33, 30, 41), 37.0),
+                                          ((29, 37, 42), 36.73), ((40, 44, 48), 100.5)])
+def test_pipeline_u16_stage2_matches_on_counts_in_every_kernel(ctx, oracle, shape, offset):
+    """stage 2 of the uint16 pipeline matches on the basic estimate rounded to counts -- in the
+    integer kernel (even rows, an offset that is exact in fp32), in the one-wave kernel for reference blocks at
+    clamped grid positions (extents - 8 that are no multiple of 4: it reads the same counts as fp32), in the
+    float kernel otherwise (odd rows, offset 36.73), and with every kernel forced off in turn: one result."""
+    vol, _ = synth_volume(shape, seed=sum(shape), as_u16=True)
+    vol[::7, ::5, ::3] = 65535                       # clamped ends of the count range
+    vol[3::7, 2::5, 1::3] = 0
+    want = oracle.bm4d_u16(vol, SIGMA, offset)
+    d_in, d_out = ctx.to_device(vol), ctx.alloc(vol.nbytes)
+    try:
+        for option, value in ((None, 0), ("bm_int", 0), ("force_generic_bm", 1)):
+            if option:
+                ctx.set_option(option, value)
+            try:
+                d_out.fill(0xEE)
+                ctx.denoise_u16(d_in, d_out, shape, SIGMA, offset)
+                ctx.sync()
+            finally:
+                if option:
+                    ctx.set_option(option, 1 - value)
+            np.testing.assert_array_equal(d_out.download(shape, np.uint16), want)
+    finally:
+        d_in.free()
+        d_out.free()
+
+
 @pytest.mark.parametrize("shape", [(8, 8, 8), (8, 9, 12), (12, 8, 8), (9, 9, 9), (16, 8, 20),
                                    (8, 64, 8), (13, 11, 10)])
 def test_tiny_and_thin_volumes_full_pipeline(ctx, oracle, shape):
