@@ -564,9 +564,13 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const long 
                                                                      size_t plane, int nz, Win1D w, float lo,
                                                                      float hi, int do_clip, float offset,
                                                                      const float* __restrict__ pair_src,
-                                                                     float* __restrict__ pair_out) {
+                                                                     float* __restrict__ pair_out,
+                                                                     uint16_t* __restrict__ match16,
+                                                                     float match_offset) {
     // pair_out (fp32 output, W = 4 only): additionally the interleaved volume (pair_src, out) the Wiener
     // kernel gathers from, so that it does not cost a pass of its own
+    // match16 (fp32 output): additionally the estimate rounded to counts, XOR 0x8000 -- what stage 2 of the
+    // uint16 pipelines matches on in the integer kernel (OpRoundCountsU16 as a pass: 2.5 ms)
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const size_t lines_per_vol = plane / W;
     for (size_t l = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; l < nlines;
@@ -619,6 +623,18 @@ __global__ __launch_bounds__(EW_THREADS) void normalize_zconv_kernel(const long 
 #pragma unroll
                 for (int j = 0; j < W; j++)
                     if (do_clip) r[j] = fminf(fmaxf(r[j], lo), hi);
+                if (match16) {
+                    uint16_t* m16 = match16 + at;
+                    if (W == 4) {
+                        const uint32_t q0 = quantise_u16(r[0] + match_offset, 65535.0f) ^ 0x8000u;
+                        const uint32_t q1 = quantise_u16(r[1 % W] + match_offset, 65535.0f) ^ 0x8000u;
+                        const uint32_t q2 = quantise_u16(r[2 % W] + match_offset, 65535.0f) ^ 0x8000u;
+                        const uint32_t q3 = quantise_u16(r[3 % W] + match_offset, 65535.0f) ^ 0x8000u;
+                        *reinterpret_cast<uint2*>(m16) = make_uint2(q0 | (q1 << 16), q2 | (q3 << 16));
+                    } else {
+                        m16[0] = (uint16_t)(quantise_u16(r[0] + match_offset, 65535.0f) ^ 0x8000u);
+                    }
+                }
                 if (W == 4) {
                     *reinterpret_cast<float4*>(o32) = make_float4(r[0], r[1 % W], r[2 % W], r[3 % W]);
                     if (pair_out) {
@@ -660,8 +676,13 @@ hipError_t launch_den_xy_from_corners(const unsigned long long* cw, float* tmp, 
 hipError_t launch_normalize_zconv(const long long* num, const double* qscale, const float* txy, float* out_f32,
                                   uint16_t* out_u16, int nz, int ny, int nx, int batch, const float* win1d,
                                   float lo, float hi, float offset, hipStream_t s, const float* pair_src,
-                                  float* pair_out, int* pair_written) {
+                                  float* pair_out, int* pair_written, uint16_t* match16, float match_offset,
+                                  int* match_written) {
     if (pair_written) *pair_written = 0;
+    if (match_written) *match_written = 0;
+    // (the rounded copy is of the UNCLIPPED fp32 estimate; 8-byte stores in the wide form)
+    if (out_u16 || lo <= hi || ((uintptr_t)match16 & 7u) != 0) match16 = nullptr;
+    if (match16 && match_written) *match_written = 1;
     Win1D w;
     for (int t = 0; t < 8; t++) w.k[t] = win1d[t];
     const size_t plane = (size_t)ny * nx;
@@ -675,18 +696,19 @@ hipError_t launch_normalize_zconv(const long long* num, const double* qscale, co
     float* nulw = nullptr;
     if (wide && out_u16) {
         hipLaunchKernelGGL((normalize_zconv_kernel<4, true>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
-                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw);
+                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw, nullptr, 0.0f);
     } else if (wide) {
         const bool pw = pair_src && pair_out && ((uintptr_t)pair_src & 15u) == 0 && ((uintptr_t)pair_out & 15u) == 0;
         hipLaunchKernelGGL((normalize_zconv_kernel<4, false>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
-                           nlines, plane, nz, w, lo, hi, clip, offset, pw ? pair_src : nul, pw ? pair_out : nulw);
+                           nlines, plane, nz, w, lo, hi, clip, offset, pw ? pair_src : nul, pw ? pair_out : nulw,
+                           match16, match_offset);
         if (pair_written && pw) *pair_written = 1;
     } else if (out_u16) {
         hipLaunchKernelGGL((normalize_zconv_kernel<1, true>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
-                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw);
+                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw, nullptr, 0.0f);
     } else {
         hipLaunchKernelGGL((normalize_zconv_kernel<1, false>), grid, dim3(EW_THREADS), 0, s, num, qscale, txy, out,
-                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw);
+                           nlines, plane, nz, w, lo, hi, clip, offset, nul, nulw, match16, match_offset);
     }
     return hipGetLastError();
 }

@@ -809,6 +809,13 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
     const float sigma2 = (float)((double)sigma * (double)sigma);
     hipStream_t s = ctx->stream;
     int pair_ready = 0;      // the first normalisation wrote the Wiener stage's (noisy, basic) volume
+    // stage 2 of a uint16 pipeline in the integer kernel?  Decided here because the first
+    // normalisation then also writes the rounded estimate (into noisy16's memory: stage 1 is done with it)
+    const bool match_use16 = match_counts && stages >= 2 && noisy16 && ctx->bm_int &&
+                             (double)p->c_match_wie * (double)sigma * (double)sigma * 512.0 < 16777216.0 &&
+                             (g.nx % 2) == 0 && offset_exact_in_fp32(match_offset) &&
+                             guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
+    int match16_ready = 0;
     if (ctx->profile)
         for (int i = 1; i < EXABM4D_PHASE_COUNT; i++) ctx->ev_used[i] = false;
     if ((noisy_guarded && !guarded_region_ok(ctx, noisy, n * sizeof(float))) ||
@@ -846,7 +853,8 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
             // ... and, where it can, the Wiener stage's interleaved (noisy, basic) volume
             HIP_TRY(ctx, launch_normalize_zconv(num, qs, tmp, basic, nullptr, g.nz, g.ny, g.nx, batch, ctx->win1d,
                                                 1.0f, 0.0f, 0.0f, s, ctx->stage.pairvol ? noisy : nullptr, pairvol,
-                                                &pair_ready));
+                                                &pair_ready, match_use16 ? const_cast<uint16_t*>(noisy16) : nullptr,
+                                                match_offset, &match16_ready));
         }
         {
             PhaseTimer t(ctx, EXABM4D_PHASE_ZERO_ACC_2);
@@ -859,13 +867,11 @@ static int run_pipeline(exabm4d_ctx* ctx, const float* noisy, float* out_f32, ui
             const uint16_t* match16 = nullptr;
             int match_guarded = 1;
             if (match_counts) {
-                const double tau512 = (double)p->c_match_wie * (double)sigma * (double)sigma * 512.0;
-                const bool use16 = noisy16 && ctx->bm_int && tau512 < 16777216.0 && (g.nx % 2) == 0 &&
-                                   offset_exact_in_fp32(match_offset) &&
-                                   guarded_region_ok(ctx, noisy16, n * sizeof(uint16_t));
+                const bool use16 = match_use16;
                 if (use16) {
                     uint16_t* m16 = const_cast<uint16_t*>(noisy16);      // our own scratch; stage 1 is done with it
-                    HIP_TRY(ctx, launch_round_counts(basic, nullptr, m16, n, match_offset, s));
+                    if (!match16_ready)                                  // (normally written by the normalisation)
+                        HIP_TRY(ctx, launch_round_counts(basic, nullptr, m16, n, match_offset, s));
                     match16 = m16;
                 }
                 // reference blocks at clamped grid positions (an extent - 8 that is no multiple of 4) go through

@@ -110,7 +110,11 @@ hipError_t launch_den_xy_from_corners(const unsigned long long* cw, float* tmp, 
 hipError_t launch_normalize_zconv(const long long* num, const double* qscale, const float* txy, float* out_f32,
                                   uint16_t* out_u16, int nz, int ny, int nx, int batch, const float* win1d,
                                   float lo, float hi, float offset, hipStream_t s, const float* pair_src = nullptr,
-                                  float* pair_out = nullptr, int* pair_written = nullptr);
+                                  float* pair_out = nullptr, int* pair_written = nullptr,
+                                  // match16 (optional, unclipped fp32 output only): also the estimate rounded to
+                                  // counts XOR 0x8000, rint(clamp(out + match_offset, 0, 65535))
+                                  uint16_t* match16 = nullptr, float match_offset = 0.0f,
+                                  int* match_written = nullptr);
 // staged entry point: num_f = fl32(fl64(num) 2^(E - 43))
 hipError_t launch_num_to_float(const long long* num, const double* qscale, float* out, size_t nvox, int batch,
                                hipStream_t s);

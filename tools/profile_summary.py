@@ -16,8 +16,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PHASES = {           # bench phase -> (kernel-name fragment, launches of it per bench step)
     "counts_from_u16": "OpCountsFromU16",
-    "blockmatch_ht": "bm_tile16_kernel",     # uint16 pipelines: the integer tile kernel
-    "blockmatch_wie": "bm_tile_kernel",
+    # uint16 pipelines: both matching passes run in the integer tile kernel (stage 2 on the basic estimate
+    # rounded to counts); its per-launch means are means over the two launches of a step
+    "blockmatch_ht": "bm_tile16_kernel",
+    "blockmatch_wie": "bm_tile16_kernel",     # (the rounded estimate is written by normalize_basic)
     "stage_ht": "stage_half_kernel<false>",
     "stage_wie": "stage_half_kernel<true>",
     # (round 3: the pipelines' normalisations carry the z pass of the denominator convolution)
@@ -31,9 +33,22 @@ PHASES = {           # bench phase -> (kernel-name fragment, launches of it per 
 }
 
 
+def newest_database_only(src):
+    """gpurun MERGES what a call wrote into the local gpurun_out/: the databases of earlier profiling rounds stay
+    next to the new ones and pmc_summary.py would average over all of them (kernels that no longer run
+    included).  Keep the newest database of every pass."""
+    import glob
+    for d in sorted(os.listdir(src)):
+        dbs = sorted(glob.glob(os.path.join(src, d, "**", "*_results.db"), recursive=True), key=os.path.getmtime)
+        for old in dbs[:-1]:
+            print("removing the database of an earlier round:", old)
+            os.remove(old)
+
+
 def main():
     src, dst, size = sys.argv[1], sys.argv[2], int(sys.argv[3])
     os.makedirs(dst, exist_ok=True)
+    newest_database_only(src)
     stats_csv = os.path.join(dst, f"kernel_stats_bench_default_{size}.csv")
     pmc_json = os.path.join(dst, f"pmc_counters_{size}.json")
     subprocess.run([sys.executable, os.path.join(HERE, "pmc_summary.py"), os.path.join(src, "trace"),
