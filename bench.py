@@ -58,8 +58,8 @@ ALGO_BYTES_PER_VOXEL = {
     "counts_from_u16": 2 + 4,
     "blockmatch_ht": 2 + 1,          # stage-1 matching reads the uint16 planes (integer kernel)
     "stage_ht": 1 + 4 + 8,
-    "normalize_basic": 8 + 4,
-    "blockmatch_wie": (4 + 2) + (2 + 1),   # the basic estimate rounded to counts, then the integer kernel
+    "normalize_basic": 8 + 4 + 2,    # ... + the estimate rounded to counts for stage 2's matching
+    "blockmatch_wie": 2 + 1,         # the integer kernel again, on those counts
     "stage_wie": 1 + 4 + 4 + 8,
     "normalize_out": 8 + 2,
     # encode legs: volume / indices read once + the packed streams written (measured per run)
