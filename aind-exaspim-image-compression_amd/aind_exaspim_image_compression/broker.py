@@ -379,8 +379,12 @@ def serve(device, idle=10.0, linger=0.002, max_voxels=1 << 30, slots=4):
 
     try:
         while True:
-            busy = any(sl.busy for sl in pool)
-            timeout = 0.25 if not pending and not busy else (linger if pending else 0.25)
+            # sleep until a message, the end of a call (wake-up pipe) or -- requests pending and a slot free --
+            # the moment the oldest request has lingered long enough
+            if pending and any(not sl.busy for sl in pool):
+                timeout = max(0.0, linger - (time.perf_counter() - first_arrival))
+            else:
+                timeout = 0.25
             ready = connection.wait([lsock, wake_r] + conns, timeout=timeout)
             for r in ready:
                 if r is lsock:

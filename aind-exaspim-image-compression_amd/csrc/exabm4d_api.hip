@@ -1254,6 +1254,7 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
     if (ctx->host_pipeline && in != out && batch >= 2 && (size_t)batch >= 2 * per && per <= 65535) {
         rc = denoise_f32_host_pipelined(ctx, in, out, nz, ny, nx, batch, (int)per, sigma, p, stages, clip_lo,
                                         clip_hi);
+        if (rc != EXABM4D_OK && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);   // nothing of it left in flight
         if (rc == EXABM4D_OK || ctx->bm.carry != 0) return rc;
         // the carry's wait ran out somewhere (it is off now): once more below, in one piece
     }
