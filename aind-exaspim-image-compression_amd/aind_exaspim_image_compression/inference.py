@@ -79,13 +79,81 @@ def _miopen_defaults():
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 
 
-def _ndhwc_shadow(model):
+class FusedGroupNormLeakyReLU(torch.nn.Module):
+    """``GroupNorm`` followed by ``LeakyReLU`` as ONE module for inference on NDHWC tensors: the pair of the
+    reference's ``DoubleConv`` (unet3d.py:137-208) through ``exabm4d_groupnorm_lrelu_ndhwc_dev`` -- statistics,
+    normalisation and activation in two passes over the layout MIOpen's convolutions produce, in place on the
+    convolution's output.  PyTorch's own GroupNorm wants NCDHW: per layer a layout copy in, statistics, apply,
+    the activation and a layout copy back (45 % of the forward's kernel time).  Falls back to the framework's
+    two modules for anything the kernels do not take (training, other dtypes / layouts / channel counts)."""
+
+    def __init__(self, norm, act):
+        super().__init__()
+        self.norm, self.act = norm, act
+        self._ws = None
+
+    def forward(self, x):
+        n = self.norm
+        fused = (not self.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5
+                 and x.is_contiguous(memory_format=torch.channels_last_3d) and not torch.is_grad_enabled()
+                 and n.num_channels % 4 == 0 and (n.num_channels // n.num_groups) % 4 == 0
+                 and 256 % (n.num_channels // 4) == 0 and n.num_groups <= 32 and x.shape[0] <= 65535)
+        if not fused:
+            return self.act(self.norm(x))
+        b, c = int(x.shape[0]), int(x.shape[1])
+        spatial = int(x.shape[2]) * int(x.shape[3]) * int(x.shape[4])
+        need = int(_native.lib().exabm4d_groupnorm_workspace_bytes(b, spatial, c, n.num_groups))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        ctx = _native.context(x.device.index or 0)
+        ctx.groupnorm_lrelu_ndhwc(torch.cuda.current_stream(x.device).cuda_stream, x, x, b, spatial, c,
+                                  n.num_groups, n.weight, n.bias, n.eps, self.act.negative_slope,
+                                  self._ws, need)
+        return x
+
+
+class _OnNCDHW(torch.nn.Module):
+    """Run ``inner`` on an NCDHW copy of its input: PyTorch's max-pool and trilinear up-sampling kernels walk an
+    NDHWC tensor through generic strides (3.8 ms per call on the U-Net's tensors against 0.3 ms + a layout
+    copy).  Four of each per forward; everything else of the NDHWC copy stays NDHWC."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, x):
+        return self.inner(x.contiguous())
+
+
+def _fuse_norm_act(module):
+    """Replace every (GroupNorm, LeakyReLU) neighbour pair inside ``nn.Sequential`` containers of ``module`` by
+    a ``FusedGroupNormLeakyReLU`` + ``Identity`` (same positions: the copy's parameters are the pair's), and
+    put every ``MaxPool3d`` / ``Upsample`` behind ``_OnNCDHW``.  For the private copy ``_ndhwc_shadow`` makes;
+    its ``state_dict`` keys are not the model's any more."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, (torch.nn.MaxPool3d, torch.nn.Upsample)):
+            setattr(module, name, _OnNCDHW(child).train(module.training))
+        else:
+            _fuse_norm_act(child)
+    if isinstance(module, torch.nn.Sequential):
+        for i in range(len(module) - 1):
+            a, b = module[i], module[i + 1]
+            if isinstance(a, torch.nn.GroupNorm) and isinstance(b, torch.nn.LeakyReLU) and a.affine:
+                module[i] = FusedGroupNormLeakyReLU(a, b).train(module.training)   # (a new module starts in training mode)
+                module[i + 1] = torch.nn.Identity()
+    return module
+
+
+def _ndhwc_shadow(model, fuse=True):
     """An NDHWC (channels_last_3d) copy of an eval-mode fp32 module for the forward passes of one ``predict``
     call: MIOpen's implicit-GEMM solvers for NDHWC weights run this U-Net at 51 TFLOP/s against 30 for the
-    default layout.  The caller's model is not touched (52 MB copied per call); same fp32 arithmetic, results
-    differ by summation order (4e-6 on the golden patch, tests at 2e-3)."""
+    default layout, and (``fuse``) its GroupNorm + LeakyReLU pairs run as the fused NDHWC kernels of
+    ``libexabm4d`` instead of converting the layout there and back around PyTorch's GroupNorm.  The caller's
+    model is not touched (52 MB copied per call); same fp32 arithmetic, results differ by summation order
+    (tests at 2e-3 against the golden patch)."""
     import copy
-    return copy.deepcopy(model).to(memory_format=torch.channels_last_3d)
+    shadow = copy.deepcopy(model).to(memory_format=torch.channels_last_3d)
+    return _fuse_norm_act(shadow) if fuse else shadow
 
 
 def tune_model(model):

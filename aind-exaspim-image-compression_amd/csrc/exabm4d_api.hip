@@ -1321,6 +1321,31 @@ int exabm4d_denoise_f32_host_v(exabm4d_ctx* ctx, const float* const* in, float* 
     }
 }
 
+// ---- BM4DNet stage: fused GroupNorm + LeakyReLU on NDHWC tensors (nn_kernels.hip) ------------------------
+size_t exabm4d_groupnorm_workspace_bytes(int batch, size_t spatial, int channels, int groups) {
+    if (batch < 1 || channels < 1 || groups < 1) return 0;
+    return groupnorm_workspace_bytes(batch, spatial, channels, groups);
+}
+int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch,
+                                      size_t spatial, int channels, int groups, const float* gamma,
+                                      const float* beta, float eps, float slope, void* workspace,
+                                      size_t workspace_bytes) {
+    if (!ctx || !x || !y || !workspace) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (batch < 1 || batch > 65535 || spatial < 1 || channels < 4 || groups < 1 || groups > 32 ||
+        channels % groups != 0 || channels % 4 != 0 || (channels / groups) % 4 != 0 || 256 % (channels / 4) != 0)
+        return fail(ctx, EXABM4D_ERR_UNSUPPORTED,
+                    "groupnorm_lrelu_ndhwc: needs channels % 4 == 0, (channels / groups) % 4 == 0, "
+                    "256 % (channels / 4) == 0 and groups <= 32 (use the framework's GroupNorm otherwise)");
+    if (workspace_bytes < groupnorm_workspace_bytes(batch, spatial, channels, groups))
+        return fail(ctx, EXABM4D_ERR_INVALID, "groupnorm_lrelu_ndhwc: workspace too small");
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace) & 15u) != 0)
+        return fail(ctx, EXABM4D_ERR_INVALID, "groupnorm_lrelu_ndhwc: 16-byte aligned tensors expected");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_groupnorm_lrelu_ndhwc(x, y, batch, spatial, channels, groups, gamma, beta, eps, slope,
+                                              workspace, (hipStream_t)hip_stream));
+    return EXABM4D_OK;
+}
+
 // Page-lock caller memory that host entry points will copy from / to many times (the broker: every worker's
 // shared-memory segment, for the life of the connection): the copies then are DMA transfers instead of staged
 // ones.  hipHostRegisterDefault; the mapping is per process, the registration per (pointer, size).

@@ -115,6 +115,12 @@ hipError_t launch_normalize_zconv(const long long* num, const double* qscale, co
                                   // counts XOR 0x8000, rint(clamp(out + match_offset, 0, 65535))
                                   uint16_t* match16 = nullptr, float match_offset = 0.0f,
                                   int* match_written = nullptr);
+// BM4DNet stage: GroupNorm + LeakyReLU on an NDHWC tensor x[batch][spatial][C] (nn_kernels.hip); y may be x.
+// Requires C % 4 == 0, (C / G) % 4 == 0, 256 % (C / 4) == 0, G <= 32.
+size_t groupnorm_workspace_bytes(int batch, size_t spatial, int C, int G);
+hipError_t launch_groupnorm_lrelu_ndhwc(const float* x, float* y, int batch, size_t spatial, int C, int G,
+                                        const float* gamma, const float* beta, float eps, float slope,
+                                        void* workspace, hipStream_t s);
 // staged entry point: num_f = fl32(fl64(num) 2^(E - 43))
 hipError_t launch_num_to_float(const long long* num, const double* qscale, float* out, size_t nvox, int batch,
                                hipStream_t s);

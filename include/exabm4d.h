@@ -298,6 +298,20 @@ int exabm4d_denoise_f32_host(exabm4d_ctx* ctx, const float* in, float* out, int 
 int exabm4d_denoise_f32_host_v(exabm4d_ctx* ctx, const float* const* in, float* const* out, int nz, int ny,
                                int nx, int batch, float sigma, const exabm4d_params* p, int stages,
                                float clip_lo, float clip_hi);
+/* ---- BM4DNet stage (reference machine_learning/unet3d.py:137-208: Conv3d -> GroupNorm(gcd(8, C)) ->
+ * LeakyReLU(0.01)): GroupNorm + LeakyReLU fused, on the NDHWC layout MIOpen's fast convolutions produce and
+ * consume.  x, y: fp32 [batch][spatial][channels] (a torch channels_last_3d tensor's memory; y may be x);
+ * groups of channels / groups consecutive channels; gamma, beta: [channels] or NULL; statistics in fp64,
+ * combined in a fixed order.  Runs on `hip_stream` (the framework's current stream), not on the context's.
+ * Implemented for channels % 4 == 0, (channels / groups) % 4 == 0, 256 % (channels / 4) == 0 and
+ * groups <= 32 (every layer of the reference's U-Net at width_multiplier 1, 2, 4); anything else returns
+ * EXABM4D_ERR_UNSUPPORTED and the caller keeps the framework's own GroupNorm.  workspace: exabm4d_groupnorm_workspace_bytes() of device memory. */
+size_t exabm4d_groupnorm_workspace_bytes(int batch, size_t spatial, int channels, int groups);
+int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch,
+                                      size_t spatial, int channels, int groups, const float* gamma,
+                                      const float* beta, float eps, float slope, void* workspace,
+                                      size_t workspace_bytes);
+
 /* Page-lock `bytes` of caller memory at `ptr` that the host entry points will copy from / to repeatedly (the
  * broker registers every worker's shared-memory segment once): copies become DMA transfers instead of staged
  * ones.  Unregister before the memory is unmapped. */

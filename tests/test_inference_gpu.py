@@ -10,6 +10,7 @@ import torch
 from oracle import host_oracle as H
 from test_oracle_golden import TILING_CASES, tiling_volume
 
+from aind_exaspim_image_compression import _native  # noqa: E402
 from aind_exaspim_image_compression import inference
 from aind_exaspim_image_compression.machine_learning import transforms as T
 from aind_exaspim_image_compression.machine_learning import unet3d
@@ -135,6 +136,58 @@ def test_ndhwc_shadow_matches_the_reference_cpu_output_and_leaves_the_model_alon
     b = inference.predict(vol, model, tf, batch_size=4, verbose=False, fast=False).astype(np.int32)
     assert np.mean(np.abs(a - b) > 1) < 1e-3
     assert w0.is_contiguous() and not model.training
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 16, 16, 16), (2, 64, 8, 9, 10), (2, 512, 4, 4, 4), (1, 128, 5, 3, 2),
+                                   (33, 32, 4, 4, 4), (2, 96, 8, 8, 8)])
+def test_fused_groupnorm_leakyrelu_on_ndhwc(shape):
+    """The BM4DNet stage's GroupNorm + LeakyReLU pairs as one NDHWC kernel pair (csrc/nn_kernels.hip) against
+    the framework's two modules: fp64 statistics here, Welford in fp32 there -- agreement to a few ulp of
+    the normalised values; the fused result is a deterministic function of its input; 96 channels (24 float4
+    lanes do not divide a workgroup) take the framework's path through the same module."""
+    b, c = shape[:2]
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 3 + 1.5).cuda().contiguous(memory_format=torch.channels_last_3d)
+    norm = torch.nn.GroupNorm(8, c).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(c, generator=g))
+        norm.bias.copy_(torch.randn(c, generator=g))
+    act = torch.nn.LeakyReLU(0.01)
+    fused = inference.FusedGroupNormLeakyReLU(norm, act).eval()
+    with torch.no_grad():
+        want = act(norm(x.contiguous())).cpu().numpy()          # the framework's NCDHW path
+        got1 = fused(x.clone()).cpu().numpy()
+        got2 = fused(x.clone()).cpu().numpy()
+    np.testing.assert_allclose(got1, want, atol=2e-5, rtol=2e-5)
+    np.testing.assert_array_equal(got1, got2)
+    with torch.no_grad():                                        # other layouts / modes: the framework's modules
+        plain = fused(x.contiguous().clone())
+    np.testing.assert_allclose(plain.cpu().numpy(), want, atol=1e-6, rtol=1e-6)
+
+
+def test_shadow_fuses_every_norm_pair_and_runs_pool_and_upsample_on_ncdhw():
+    torch.manual_seed(0)
+    model = unet3d.UNet().cuda().eval()
+    shadow = inference._ndhwc_shadow(model)
+    fused = [m for m in shadow.modules() if isinstance(m, inference.FusedGroupNormLeakyReLU)]
+    assert len(fused) == 18 and not any(isinstance(m, inference.FusedGroupNormLeakyReLU) for m in model.modules())
+    assert not any(m.training for m in fused)            # the copies of an eval-mode model take the fused kernels
+    assert sum(isinstance(m, inference._OnNCDHW) for m in shadow.modules()) == 8
+    assert len(model.state_dict()) == len(shadow.state_dict())
+    calls = []
+    real = _native.Context.groupnorm_lrelu_ndhwc
+    _native.Context.groupnorm_lrelu_ndhwc = lambda self, *a, **k: (calls.append(a[4]), real(self, *a, **k))[1]
+    try:
+        with torch.no_grad():
+            shadow(torch.zeros(1, 1, 16, 16, 16, device="cuda"))
+    finally:
+        _native.Context.groupnorm_lrelu_ndhwc = real
+    assert len(calls) == 18
+    plain = inference._ndhwc_shadow(model, fuse=False)
+    x = torch.randn(2, 1, 32, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        a, b = shadow(x).cpu().numpy(), plain(x).cpu().numpy()
+    np.testing.assert_allclose(a, b, atol=2e-4, rtol=1e-4)
 
 
 def test_n2v2_on_rocm_and_shape_contract():

@@ -9,7 +9,7 @@ src=${SRC:-$here/../../aind-exaspim-image-compression_amd/csrc}
 out=$here/variants
 mkdir -p "$out/obj_$name"
 flags="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off"
-for f in exabm4d_api comm_rccl bm_kernels stage_kernels elementwise_kernels metrics_kernels codec_kernels rans_kernels rans2_kernels; do
+for f in exabm4d_api comm_rccl bm_kernels stage_kernels elementwise_kernels metrics_kernels codec_kernels rans_kernels rans2_kernels nn_kernels; do
   /opt/rocm/bin/hipcc $flags "$@" -c "$src/$f.hip" -o "$out/obj_$name/$f.o" &
 done
 wait
