@@ -118,6 +118,8 @@ SIGNATURES = {
     "exabm4d_denoise_f32_host_v": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_groupnorm_workspace_bytes": (_SZ, [_I, _SZ, _I, _I]),
     "exabm4d_groupnorm_lrelu_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _SZ, _I, _I, c_vp, c_vp, _F, _F, c_vp, _SZ]),
+    "exabm4d_maxpool2_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _I]),
+    "exabm4d_upsample2_trilinear_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _I]),
     "exabm4d_host_register": (_I, [_CTX, c_vp, ctypes.c_size_t]),
     "exabm4d_host_unregister": (_I, [_CTX, c_vp]),
     "exabm4d_transform_forward_u16_dev": (_I, [_CTX, _TP, c_vp, c_vp, _SZ]),
@@ -476,6 +478,14 @@ class Context:
             self.handle, int(stream), _ptr(x), _ptr(y), int(batch), int(spatial), int(channels), int(groups),
             _ptr(gamma) if gamma is not None else None, _ptr(beta) if beta is not None else None,
             float(eps), float(slope), _ptr(workspace), int(workspace_bytes)))
+
+    def maxpool2_ndhwc(self, stream, x, y, batch, d, h, w, channels):
+        self._check(lib().exabm4d_maxpool2_ndhwc_dev(self.handle, int(stream), _ptr(x), _ptr(y), int(batch), int(d),
+                                                     int(h), int(w), int(channels)))
+
+    def upsample2_trilinear_ndhwc(self, stream, x, y, batch, d, h, w, channels):
+        self._check(lib().exabm4d_upsample2_trilinear_ndhwc_dev(self.handle, int(stream), _ptr(x), _ptr(y),
+                                                                int(batch), int(d), int(h), int(w), int(channels)))
 
     def host_register(self, addr, nbytes):
         """Page-lock caller memory that host entry points copy from / to repeatedly (see the header)."""

@@ -112,27 +112,60 @@ class FusedGroupNormLeakyReLU(torch.nn.Module):
         return x
 
 
-class _OnNCDHW(torch.nn.Module):
-    """Run ``inner`` on an NCDHW copy of its input: PyTorch's max-pool and trilinear up-sampling kernels walk an
-    NDHWC tensor through generic strides (3.8 ms per call on the U-Net's tensors against 0.3 ms + a layout
-    copy).  Four of each per forward; everything else of the NDHWC copy stays NDHWC."""
+def _all_equal(v, want):
+    return all(x == want for x in (v if isinstance(v, (tuple, list)) else (v,)))
+
+
+class _ResampleNDHWC(torch.nn.Module):
+    """The U-Net's ``MaxPool3d(2)`` and ``Upsample(scale_factor=2, mode="trilinear", align_corners=True)`` on
+    NDHWC tensors through ``libexabm4d`` (csrc/nn_kernels.hip: a float4 of channels per thread).  PyTorch's own
+    kernels for the two walk an NDHWC tensor through generic strides (3.8 ms per call on this U-Net's tensors);
+    anything else -- other parameters, layouts, dtypes, training -- runs ``inner`` on an NCDHW copy."""
 
     def __init__(self, inner):
         super().__init__()
         self.inner = inner
+        m = inner
+        if isinstance(m, torch.nn.MaxPool3d):
+            ok = (_all_equal(m.kernel_size, 2) and _all_equal(m.stride if m.stride is not None else m.kernel_size, 2)
+                  and _all_equal(m.padding, 0) and _all_equal(m.dilation, 1) and not m.ceil_mode
+                  and not m.return_indices)
+            self.kind = "pool" if ok else None
+        elif isinstance(m, torch.nn.Upsample):
+            ok = (m.mode == "trilinear" and m.align_corners is True and m.size is None
+                  and m.scale_factor is not None and _all_equal(m.scale_factor, 2))
+            self.kind = "up" if ok else None
+        else:
+            self.kind = None
 
     def forward(self, x):
-        return self.inner(x.contiguous())
+        native = (self.kind is not None and not self.training and not torch.is_grad_enabled() and x.is_cuda
+                  and x.dtype == torch.float32 and x.dim() == 5 and x.shape[1] % 4 == 0
+                  and x.is_contiguous(memory_format=torch.channels_last_3d)
+                  and (self.kind == "up" or min(x.shape[2:]) >= 2))
+        if not native:
+            return self.inner(x.contiguous())
+        b, c, d, h, w = (int(v) for v in x.shape)
+        out_dims = (d // 2, h // 2, w // 2) if self.kind == "pool" else (2 * d, 2 * h, 2 * w)
+        y = torch.empty((b, c) + out_dims, dtype=torch.float32, device=x.device,
+                        memory_format=torch.channels_last_3d)
+        ctx = _native.context(x.device.index or 0)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        if self.kind == "pool":
+            ctx.maxpool2_ndhwc(stream, x, y, b, d, h, w, c)
+        else:
+            ctx.upsample2_trilinear_ndhwc(stream, x, y, b, d, h, w, c)
+        return y
 
 
 def _fuse_norm_act(module):
     """Replace every (GroupNorm, LeakyReLU) neighbour pair inside ``nn.Sequential`` containers of ``module`` by
     a ``FusedGroupNormLeakyReLU`` + ``Identity`` (same positions: the copy's parameters are the pair's), and
-    put every ``MaxPool3d`` / ``Upsample`` behind ``_OnNCDHW``.  For the private copy ``_ndhwc_shadow`` makes;
+    put every ``MaxPool3d`` / ``Upsample`` behind ``_ResampleNDHWC``.  For the private copy ``_ndhwc_shadow`` makes;
     its ``state_dict`` keys are not the model's any more."""
     for name, child in list(module.named_children()):
         if isinstance(child, (torch.nn.MaxPool3d, torch.nn.Upsample)):
-            setattr(module, name, _OnNCDHW(child).train(module.training))
+            setattr(module, name, _ResampleNDHWC(child).train(module.training))
         else:
             _fuse_norm_act(child)
     if isinstance(module, torch.nn.Sequential):

@@ -1346,6 +1346,31 @@ int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const 
     return EXABM4D_OK;
 }
 
+static int nn_resample_checks(exabm4d_ctx* ctx, const void* x, const void* y, int batch, int d, int h, int w,
+                              int channels) {
+    if (!ctx || !x || !y) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (batch < 1 || d < 1 || h < 1 || w < 1 || channels < 4 || channels % 4 != 0)
+        return fail(ctx, EXABM4D_ERR_UNSUPPORTED, "NDHWC resampling: sizes >= 1 and channels % 4 == 0");
+    if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0)
+        return fail(ctx, EXABM4D_ERR_INVALID, "NDHWC resampling: 16-byte aligned tensors expected");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return EXABM4D_OK;
+}
+int exabm4d_maxpool2_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch, int d,
+                               int h, int w, int channels) {
+    int rc = nn_resample_checks(ctx, x, y, batch, d, h, w, channels);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_maxpool2_ndhwc(x, y, batch, d, h, w, channels, (hipStream_t)hip_stream));
+    return EXABM4D_OK;
+}
+int exabm4d_upsample2_trilinear_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch,
+                                          int d, int h, int w, int channels) {
+    int rc = nn_resample_checks(ctx, x, y, batch, d, h, w, channels);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_upsample2_trilinear_ndhwc(x, y, batch, d, h, w, channels, (hipStream_t)hip_stream));
+    return EXABM4D_OK;
+}
+
 // Page-lock caller memory that host entry points will copy from / to many times (the broker: every worker's
 // shared-memory segment, for the life of the connection): the copies then are DMA transfers instead of staged
 // ones.  hipHostRegisterDefault; the mapping is per process, the registration per (pointer, size).

@@ -121,6 +121,102 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const float* __res
     }
 }
 
+// ---- MaxPool3d(2) and trilinear x2 up-sampling (align_corners = True) on NDHWC ---------------------------
+// The U-Net's four down- and four up-samplings (reference unet3d.py:211-342).  PyTorch's kernels for these walk
+// an NDHWC tensor through generic strides (3.8 ms per call here) or want an NCDHW copy; a float4 of channels per
+// thread makes both trivially coalesced on the layout the convolutions use.
+__device__ __forceinline__ float max_nan(float a, float b) { return (b > a || b != b) ? b : a; }   // NaN wins, as in torch
+__global__ __launch_bounds__(GN_THREADS) void maxpool2_ndhwc_kernel(const float4* __restrict__ x,
+                                                                   float4* __restrict__ y, size_t total, int OD,
+                                                                   int OH, int OW, int H, int W, int D, int lanes) {
+    for (size_t o = (size_t)blockIdx.x * GN_THREADS + threadIdx.x; o < total; o += (size_t)gridDim.x * GN_THREADS) {
+        const int l = (int)(o % lanes);
+        size_t t = o / lanes;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH); t /= OH;
+        const int od = (int)(t % OD);
+        const size_t b = t / OD;
+        const float4* p = x + ((((b * D + 2 * od) * H + 2 * oh) * (size_t)W + 2 * ow) * lanes + l);
+        float4 m = p[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+            const float4 v = p[(((size_t)(k >> 2) * H + ((k >> 1) & 1)) * W + (k & 1)) * lanes];
+            m.x = max_nan(m.x, v.x); m.y = max_nan(m.y, v.y); m.z = max_nan(m.z, v.z); m.w = max_nan(m.w, v.w);
+        }
+        y[o] = m;
+    }
+}
+hipError_t launch_maxpool2_ndhwc(const float* x, float* y, int batch, int D, int H, int W, int C, hipStream_t s) {
+    const int OD = D / 2, OH = H / 2, OW = W / 2, lanes = C / 4;
+    const size_t total = (size_t)batch * OD * OH * OW * lanes;
+    if (total == 0) return hipSuccess;
+    size_t blocks = (total + GN_THREADS - 1) / GN_THREADS;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(maxpool2_ndhwc_kernel, dim3((unsigned)blocks), dim3(GN_THREADS), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), total, OD, OH, OW, H, W, D,
+                       lanes);
+    return hipGetLastError();
+}
+
+// out extent = 2 * in; source coordinate r * o with r = (in - 1) / (out - 1) in fp32, i0 = (int)(r o),
+// i1 = i0 + (i0 < in - 1), weights (1 - lambda, lambda): PyTorch's upsample_trilinear3d with align_corners
+struct UpAxis {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ UpAxis up_axis(int o, int in, float r) {
+    const float src = r * (float)o;
+    UpAxis a;
+    a.i0 = (int)src;
+    a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
+    a.w1 = src - (float)a.i0;
+    a.w0 = 1.0f - a.w1;
+    return a;
+}
+__global__ __launch_bounds__(GN_THREADS) void upsample2_ndhwc_kernel(const float4* __restrict__ x,
+                                                                    float4* __restrict__ y, size_t total, int D,
+                                                                    int H, int W, int lanes, float rd, float rh,
+                                                                    float rw) {
+    const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+    for (size_t o = (size_t)blockIdx.x * GN_THREADS + threadIdx.x; o < total; o += (size_t)gridDim.x * GN_THREADS) {
+        const int l = (int)(o % lanes);
+        size_t t = o / lanes;
+        const int ow = (int)(t % OW); t /= OW;
+        const int oh = (int)(t % OH); t /= OH;
+        const int od = (int)(t % OD);
+        const size_t b = t / OD;
+        const UpAxis ad = up_axis(od, D, rd), ah = up_axis(oh, H, rh), aw = up_axis(ow, W, rw);
+        const float4* base = x + (b * D * H * (size_t)W) * lanes + l;
+        auto at = [&](int d, int h, int w) { return base[(((size_t)d * H + h) * W + w) * lanes]; };
+        auto lerp_w = [&](int d, int h) {
+            const float4 a = at(d, h, aw.i0), c = at(d, h, aw.i1);
+            return make_float4(aw.w0 * a.x + aw.w1 * c.x, aw.w0 * a.y + aw.w1 * c.y, aw.w0 * a.z + aw.w1 * c.z,
+                               aw.w0 * a.w + aw.w1 * c.w);
+        };
+        auto lerp_h = [&](int d) {
+            const float4 a = lerp_w(d, ah.i0), c = lerp_w(d, ah.i1);
+            return make_float4(ah.w0 * a.x + ah.w1 * c.x, ah.w0 * a.y + ah.w1 * c.y, ah.w0 * a.z + ah.w1 * c.z,
+                               ah.w0 * a.w + ah.w1 * c.w);
+        };
+        const float4 a = lerp_h(ad.i0), c = lerp_h(ad.i1);
+        y[o] = make_float4(ad.w0 * a.x + ad.w1 * c.x, ad.w0 * a.y + ad.w1 * c.y, ad.w0 * a.z + ad.w1 * c.z,
+                           ad.w0 * a.w + ad.w1 * c.w);
+    }
+}
+hipError_t launch_upsample2_trilinear_ndhwc(const float* x, float* y, int batch, int D, int H, int W, int C,
+                                            hipStream_t s) {
+    const int lanes = C / 4;
+    const size_t total = (size_t)batch * (2 * (size_t)D) * (2 * (size_t)H) * (2 * (size_t)W) * lanes;
+    if (total == 0) return hipSuccess;
+    auto ratio = [](int in) { return 2 * in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.0f; };
+    size_t blocks = (total + GN_THREADS - 1) / GN_THREADS;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(upsample2_ndhwc_kernel, dim3((unsigned)blocks), dim3(GN_THREADS), 0, s,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(y), total, D, H, W, lanes,
+                       ratio(D), ratio(H), ratio(W));
+    return hipGetLastError();
+}
+
 size_t groupnorm_workspace_bytes(int batch, size_t spatial, int C, int G) {
     // partial sums (at most 64 chunks per sample) + the two parameter arrays
     return (size_t)batch * 64 * (size_t)G * 2 * sizeof(double) + 2 * (size_t)batch * C * sizeof(float);

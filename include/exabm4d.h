@@ -312,6 +312,14 @@ int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const 
                                       const float* beta, float eps, float slope, void* workspace,
                                       size_t workspace_bytes);
 
+/* The U-Net's resampling layers on NDHWC fp32 tensors (reference unet3d.py:211-255 MaxPool3d(2), :258-342
+ * Upsample(scale_factor=2, mode="trilinear", align_corners=True)): x[batch][d][h][w][channels] ->
+ * y[batch][d/2][h/2][w/2][channels] (floor) resp. y[batch][2d][2h][2w][channels]; channels % 4 == 0. */
+int exabm4d_maxpool2_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch, int d,
+                               int h, int w, int channels);
+int exabm4d_upsample2_trilinear_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch,
+                                          int d, int h, int w, int channels);
+
 /* Page-lock `bytes` of caller memory at `ptr` that the host entry points will copy from / to repeatedly (the
  * broker registers every worker's shared-memory segment once): copies become DMA transfers instead of staged
  * ones.  Unregister before the memory is unmapped. */

@@ -165,14 +165,37 @@ def test_fused_groupnorm_leakyrelu_on_ndhwc(shape):
     np.testing.assert_allclose(plain.cpu().numpy(), want, atol=1e-6, rtol=1e-6)
 
 
-def test_shadow_fuses_every_norm_pair_and_runs_pool_and_upsample_on_ncdhw():
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16, 16), (3, 64, 9, 7, 10), (1, 256, 2, 2, 2), (2, 8, 5, 6, 7)])
+def test_ndhwc_maxpool_and_trilinear_upsample(shape):
+    """MaxPool3d(2) and Upsample(2, trilinear, align_corners) on NDHWC tensors (csrc/nn_kernels.hip) against
+    PyTorch's kernels on the NCDHW copy: the maximum exactly, the interpolation to rounding (same formula,
+    same fp32 ratio; the framework's build may contract multiply-adds)."""
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).cuda()
+    xl = x.contiguous(memory_format=torch.channels_last_3d)
+    pool, up = torch.nn.MaxPool3d(2), torch.nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
+    with torch.no_grad():
+        for inner, exact in ((pool, True), (up, False)):
+            mod = inference._ResampleNDHWC(inner).eval()
+            assert mod.kind is not None
+            got, want = mod(xl), inner(x)
+            assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last_3d)
+            if exact:
+                assert torch.equal(got, want)
+            else:
+                np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-6, rtol=2e-6)
+            np.testing.assert_allclose(mod(x).cpu().numpy(), want.cpu().numpy(), atol=2e-6, rtol=2e-6)   # NCDHW in: the framework's path
+    assert inference._ResampleNDHWC(torch.nn.MaxPool3d(3)).kind is None
+    assert inference._ResampleNDHWC(torch.nn.Upsample(scale_factor=2, mode="nearest")).kind is None
+
+
+def test_shadow_fuses_every_norm_pair_and_resamples_on_ndhwc():
     torch.manual_seed(0)
     model = unet3d.UNet().cuda().eval()
     shadow = inference._ndhwc_shadow(model)
     fused = [m for m in shadow.modules() if isinstance(m, inference.FusedGroupNormLeakyReLU)]
     assert len(fused) == 18 and not any(isinstance(m, inference.FusedGroupNormLeakyReLU) for m in model.modules())
     assert not any(m.training for m in fused)            # the copies of an eval-mode model take the fused kernels
-    assert sum(isinstance(m, inference._OnNCDHW) for m in shadow.modules()) == 8
+    assert sum(isinstance(m, inference._ResampleNDHWC) and m.kind is not None for m in shadow.modules()) == 8
     assert len(model.state_dict()) == len(shadow.state_dict())
     calls = []
     real = _native.Context.groupnorm_lrelu_ndhwc
