@@ -351,7 +351,8 @@ def bm4dnet_leg(vol, tune_edge=0):
         "what": f"inference.predict on the {edge}^3 uint16 bench volume: asinh transform, {npatch} patches "
                 "of 64^3 (overlap 12, trim 5), batch 32, fp32 U-Net (12.9 M parameters, random init) through "
                 "an NDHWC copy with MIOpen's tuned implicit-GEMM solvers (shipped find-db records, FAST find "
-                "mode), stitching and inverse transform on device, host to host, one timed call",
+                "mode) whose GroupNorm + LeakyReLU pairs, max-pools and up-samplings are libexabm4d's NDHWC "
+                "kernels, stitching and inverse transform on device, host to host, one timed call",
         "seconds": round(dt, 3),
         "cold_start_seconds": round(warm, 3),
         "voxels_per_s": vol.size / dt,
