@@ -117,7 +117,8 @@ SIGNATURES = {
     "exabm4d_denoise_f32_host": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_denoise_f32_host_v": (_I, [_CTX, c_vp, c_vp, _I, _I, _I, _I, _F, _PP, _I, _F, _F]),
     "exabm4d_groupnorm_workspace_bytes": (_SZ, [_I, _SZ, _I, _I]),
-    "exabm4d_groupnorm_lrelu_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _SZ, _I, _I, c_vp, c_vp, _F, _F, c_vp, _SZ]),
+    "exabm4d_groupnorm_lrelu_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _SZ, _I, _I, c_vp, c_vp, _F, _F, c_vp, _SZ,
+                                                c_vp]),
     "exabm4d_maxpool2_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _I]),
     "exabm4d_upsample2_trilinear_ndhwc_dev": (_I, [_CTX, c_vp, c_vp, c_vp, _I, _I, _I, _I, _I]),
     "exabm4d_host_register": (_I, [_CTX, c_vp, ctypes.c_size_t]),
@@ -470,14 +471,15 @@ class Context:
 
     # -- BM4DNet stage ---------------------------------------------------------------------------
     def groupnorm_lrelu_ndhwc(self, stream, x, y, batch, spatial, channels, groups, gamma, beta, eps, slope,
-                              workspace, workspace_bytes):
+                              workspace, workspace_bytes, conv_bias=None):
         """GroupNorm + LeakyReLU on an NDHWC fp32 tensor (x, y, gamma, beta, workspace: device pointers or
         objects with ``data_ptr()``; ``stream``: the HIP stream handle to run on).  ValueError where the
         fused kernels do not apply (see the header)."""
         self._check(lib().exabm4d_groupnorm_lrelu_ndhwc_dev(
             self.handle, int(stream), _ptr(x), _ptr(y), int(batch), int(spatial), int(channels), int(groups),
             _ptr(gamma) if gamma is not None else None, _ptr(beta) if beta is not None else None,
-            float(eps), float(slope), _ptr(workspace), int(workspace_bytes)))
+            float(eps), float(slope), _ptr(workspace), int(workspace_bytes),
+            _ptr(conv_bias) if conv_bias is not None else None))
 
     def maxpool2_ndhwc(self, stream, x, y, batch, d, h, w, channels):
         self._check(lib().exabm4d_maxpool2_ndhwc_dev(self.handle, int(stream), _ptr(x), _ptr(y), int(batch), int(d),

@@ -87,9 +87,12 @@ class FusedGroupNormLeakyReLU(torch.nn.Module):
     the activation and a layout copy back (45 % of the forward's kernel time).  Falls back to the framework's
     two modules for anything the kernels do not take (training, other dtypes / layouts / channel counts)."""
 
-    def __init__(self, norm, act):
+    def __init__(self, norm, act, conv_bias=None):
+        """``conv_bias``: the bias of the convolution in front, taken over from it (the caller sets that
+        convolution's ``bias`` to None): added inside the kernels instead of in a pass of its own."""
         super().__init__()
         self.norm, self.act = norm, act
+        self.conv_bias = conv_bias
         self._ws = None
 
     def forward(self, x):
@@ -99,6 +102,8 @@ class FusedGroupNormLeakyReLU(torch.nn.Module):
                  and n.num_channels % 4 == 0 and (n.num_channels // n.num_groups) % 4 == 0
                  and 256 % (n.num_channels // 4) == 0 and n.num_groups <= 32 and x.shape[0] <= 65535)
         if not fused:
+            if self.conv_bias is not None:
+                x = x + self.conv_bias.view(1, -1, 1, 1, 1)
             return self.act(self.norm(x))
         b, c = int(x.shape[0]), int(x.shape[1])
         spatial = int(x.shape[2]) * int(x.shape[3]) * int(x.shape[4])
@@ -108,7 +113,7 @@ class FusedGroupNormLeakyReLU(torch.nn.Module):
         ctx = _native.context(x.device.index or 0)
         ctx.groupnorm_lrelu_ndhwc(torch.cuda.current_stream(x.device).cuda_stream, x, x, b, spatial, c,
                                   n.num_groups, n.weight, n.bias, n.eps, self.act.negative_slope,
-                                  self._ws, need)
+                                  self._ws, need, self.conv_bias)
         return x
 
 
@@ -172,7 +177,11 @@ def _fuse_norm_act(module):
         for i in range(len(module) - 1):
             a, b = module[i], module[i + 1]
             if isinstance(a, torch.nn.GroupNorm) and isinstance(b, torch.nn.LeakyReLU) and a.affine:
-                module[i] = FusedGroupNormLeakyReLU(a, b).train(module.training)   # (a new module starts in training mode)
+                conv = module[i - 1] if i > 0 else None
+                bias = None
+                if isinstance(conv, torch.nn.Conv3d) and conv.bias is not None and conv.out_channels == a.num_channels:
+                    bias, conv.bias = conv.bias, None             # added inside the fused kernels instead
+                module[i] = FusedGroupNormLeakyReLU(a, b, bias).train(module.training)   # (a new module starts in training mode)
                 module[i + 1] = torch.nn.Identity()
     return module
 

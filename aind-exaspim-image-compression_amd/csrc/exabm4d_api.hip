@@ -1329,8 +1329,10 @@ size_t exabm4d_groupnorm_workspace_bytes(int batch, size_t spatial, int channels
 int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch,
                                       size_t spatial, int channels, int groups, const float* gamma,
                                       const float* beta, float eps, float slope, void* workspace,
-                                      size_t workspace_bytes) {
+                                      size_t workspace_bytes, const float* conv_bias) {
     if (!ctx || !x || !y || !workspace) return fail(ctx, EXABM4D_ERR_INVALID, "NULL argument");
+    if (conv_bias && ((uintptr_t)conv_bias & 15u) != 0)
+        return fail(ctx, EXABM4D_ERR_INVALID, "groupnorm_lrelu_ndhwc: conv_bias must be 16-byte aligned");
     if (batch < 1 || batch > 65535 || spatial < 1 || channels < 4 || groups < 1 || groups > 32 ||
         channels % groups != 0 || channels % 4 != 0 || (channels / groups) % 4 != 0 || 256 % (channels / 4) != 0)
         return fail(ctx, EXABM4D_ERR_UNSUPPORTED,
@@ -1342,7 +1344,7 @@ int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const 
         return fail(ctx, EXABM4D_ERR_INVALID, "groupnorm_lrelu_ndhwc: 16-byte aligned tensors expected");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_groupnorm_lrelu_ndhwc(x, y, batch, spatial, channels, groups, gamma, beta, eps, slope,
-                                              workspace, (hipStream_t)hip_stream));
+                                              workspace, (hipStream_t)hip_stream, conv_bias));
     return EXABM4D_OK;
 }
 

@@ -120,7 +120,7 @@ hipError_t launch_normalize_zconv(const long long* num, const double* qscale, co
 size_t groupnorm_workspace_bytes(int batch, size_t spatial, int C, int G);
 hipError_t launch_groupnorm_lrelu_ndhwc(const float* x, float* y, int batch, size_t spatial, int C, int G,
                                         const float* gamma, const float* beta, float eps, float slope,
-                                        void* workspace, hipStream_t s);
+                                        void* workspace, hipStream_t s, const float* cbias = nullptr);
 // MaxPool3d(2) (floor) and trilinear x2 up-sampling (align_corners) on NDHWC fp32 tensors, C % 4 == 0
 hipError_t launch_maxpool2_ndhwc(const float* x, float* y, int batch, int D, int H, int W, int C, hipStream_t s);
 hipError_t launch_upsample2_trilinear_ndhwc(const float* x, float* y, int batch, int D, int H, int W, int C,

@@ -23,7 +23,10 @@ constexpr int GN_THREADS = 256;
 // Partial sums of one (sample, chunk of rows): part[((b * nchunk + chunk) * G + g) * 2 + {0: sum, 1: sum of squares}]
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __restrict__ x, size_t spatial, int C,
                                                              int G, int nchunk, size_t rows_per_chunk,
-                                                             double* __restrict__ part) {
+                                                             double* __restrict__ part,
+                                                             const float* __restrict__ cbias) {
+    // cbias (optional): the preceding convolution's bias, added here instead of in a pass of its own --
+    // the statistics are those of x + cbias[c]
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int lanes = C / 4;                         // float4 lanes per row
     const int rows_per_iter = GN_THREADS / lanes;    // lanes divides GN_THREADS (C in {16 ... 1024}, power of two)
@@ -32,17 +35,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
     const size_t r1 = r0 + rows_per_chunk < spatial ? r0 + rows_per_chunk : spatial;
     const float4* base = reinterpret_cast<const float4*>(x + (size_t)b * spatial * C) + lane;
     float s0 = 0.0f, s1 = 0.0f, q0 = 0.0f, q1 = 0.0f;     // two accumulators each: shorter dependency chains
+    const float4 cb = cbias ? reinterpret_cast<const float4*>(cbias)[lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto ld = [&](size_t row) {
+        float4 v = base[row * lanes];
+        v.x += cb.x; v.y += cb.y; v.z += cb.z; v.w += cb.w;
+        return v;
+    };
     size_t r = r0 + rsub;
     for (; r + rows_per_iter < r1; r += 2 * (size_t)rows_per_iter) {
-        const float4 a = base[r * lanes];
-        const float4 c = base[(r + rows_per_iter) * lanes];
+        const float4 a = ld(r);
+        const float4 c = ld(r + rows_per_iter);
         s0 += (a.x + a.y) + (a.z + a.w);
         q0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
         s1 += (c.x + c.y) + (c.z + c.w);
         q1 += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
     }
     if (r < r1) {
-        const float4 a = base[r * lanes];
+        const float4 a = ld(r);
         s0 += (a.x + a.y) + (a.z + a.w);
         q0 += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
     }
@@ -68,7 +77,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const float* __res
 // a[b][c] = rstd * gamma[c], sh[b][c] = beta[c] - mean * a[b][c]   (y = a x + sh, as PyTorch's fused parameters)
 __global__ void gn_params_kernel(const double* __restrict__ part, int batch, int C, int G, int nchunk,
                                  double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 float eps, float* __restrict__ a, float* __restrict__ shift) {
+                                 float eps, float* __restrict__ a, float* __restrict__ shift,
+                                 const float* __restrict__ cbias) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch * C) return;
     const int b = i / C, c = i - b * C, g = c / (C / G);
@@ -85,7 +95,8 @@ __global__ void gn_params_kernel(const double* __restrict__ part, int batch, int
     const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
     const float av = rstd * ga;
     a[i] = av;
-    shift[i] = be - (float)mean * av;
+    // y = av (x + cbias - mean) + beta = av x + (beta + av (cbias - mean))
+    shift[i] = be + av * ((cbias ? cbias[c] : 0.0f) - (float)mean);
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -224,7 +235,7 @@ size_t groupnorm_workspace_bytes(int batch, size_t spatial, int C, int G) {
 
 hipError_t launch_groupnorm_lrelu_ndhwc(const float* x, float* y, int batch, size_t spatial, int C, int G,
                                         const float* gamma, const float* beta, float eps, float slope,
-                                        void* workspace, hipStream_t s) {
+                                        void* workspace, hipStream_t s, const float* cbias) {
     const int lanes = C / 4;
     const int rows_per_iter = GN_THREADS / lanes;
     // chunks: enough workgroups for the chip (>= ~2048 in all), at least 2 * rows_per_iter rows each, at most 64
@@ -240,10 +251,10 @@ hipError_t launch_groupnorm_lrelu_ndhwc(const float* x, float* y, int batch, siz
     float* a = reinterpret_cast<float*>(part + (size_t)batch * 64 * G * 2);
     float* shift = a + (size_t)batch * C;
     hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nchunk, (unsigned)batch), dim3(GN_THREADS), 0, s, x, spatial,
-                       C, G, (int)nchunk, rows_per_chunk, part);
+                       C, G, (int)nchunk, rows_per_chunk, part, cbias);
     const int total = batch * C;
     hipLaunchKernelGGL(gn_params_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, batch, C, G,
-                       (int)nchunk, (double)spatial * (double)(C / G), gamma, beta, eps, a, shift);
+                       (int)nchunk, (double)spatial * (double)(C / G), gamma, beta, eps, a, shift, cbias);
     const size_t n4 = spatial * (size_t)lanes;
     size_t blocks = (n4 + GN_THREADS - 1) / GN_THREADS;
     const size_t cap = (8192 + (size_t)batch - 1) / (size_t)batch;

@@ -302,7 +302,9 @@ int exabm4d_denoise_f32_host_v(exabm4d_ctx* ctx, const float* const* in, float* 
  * LeakyReLU(0.01)): GroupNorm + LeakyReLU fused, on the NDHWC layout MIOpen's fast convolutions produce and
  * consume.  x, y: fp32 [batch][spatial][channels] (a torch channels_last_3d tensor's memory; y may be x);
  * groups of channels / groups consecutive channels; gamma, beta: [channels] or NULL; statistics in fp64,
- * combined in a fixed order.  Runs on `hip_stream` (the framework's current stream), not on the context's.
+ * combined in a fixed order.  conv_bias ([channels] or NULL): the preceding convolution's bias, added on the
+ * fly -- y = lrelu(GN(x + conv_bias)) -- so that it does not cost a pass of its own.
+ * Runs on `hip_stream` (the framework's current stream), not on the context's.
  * Implemented for channels % 4 == 0, (channels / groups) % 4 == 0, 256 % (channels / 4) == 0 and
  * groups <= 32 (every layer of the reference's U-Net at width_multiplier 1, 2, 4); anything else returns
  * EXABM4D_ERR_UNSUPPORTED and the caller keeps the framework's own GroupNorm.  workspace: exabm4d_groupnorm_workspace_bytes() of device memory. */
@@ -310,7 +312,7 @@ size_t exabm4d_groupnorm_workspace_bytes(int batch, size_t spatial, int channels
 int exabm4d_groupnorm_lrelu_ndhwc_dev(exabm4d_ctx* ctx, void* hip_stream, const float* x, float* y, int batch,
                                       size_t spatial, int channels, int groups, const float* gamma,
                                       const float* beta, float eps, float slope, void* workspace,
-                                      size_t workspace_bytes);
+                                      size_t workspace_bytes, const float* conv_bias);
 
 /* The U-Net's resampling layers on NDHWC fp32 tensors (reference unet3d.py:211-255 MaxPool3d(2), :258-342
  * Upsample(scale_factor=2, mode="trilinear", align_corners=True)): x[batch][d][h][w][channels] ->

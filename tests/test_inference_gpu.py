@@ -163,6 +163,13 @@ def test_fused_groupnorm_leakyrelu_on_ndhwc(shape):
     with torch.no_grad():                                        # other layouts / modes: the framework's modules
         plain = fused(x.contiguous().clone())
     np.testing.assert_allclose(plain.cpu().numpy(), want, atol=1e-6, rtol=1e-6)
+    # with the preceding convolution's bias folded in: lrelu(GN(x + bias)), no pass for the addition
+    bias = torch.nn.Parameter((torch.randn(c, generator=g) * 2).cuda())
+    with_bias = inference.FusedGroupNormLeakyReLU(norm, act, bias).eval()
+    with torch.no_grad():
+        want_b = act(norm(x.contiguous() + bias.view(1, -1, 1, 1, 1))).cpu().numpy()
+        np.testing.assert_allclose(with_bias(x.clone()).cpu().numpy(), want_b, atol=3e-5, rtol=3e-5)
+        np.testing.assert_allclose(with_bias(x.contiguous().clone()).cpu().numpy(), want_b, atol=1e-6, rtol=1e-6)
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 16, 16, 16), (3, 64, 9, 7, 10), (1, 256, 2, 2, 2), (2, 8, 5, 6, 7)])
